@@ -1,0 +1,142 @@
+"""CPU tests: pin the C restatement (oracle/ndsm_oracle.c) to the reference.
+
+(a) committed golden vectors produced by the reference itself
+    (tests/golden/make_golden.py), (b) the reference's own known-answer rows
+    tests/integration_test/results_test1.txt:6-7, (c) the live reference on
+    fresh random inputs when oracle/_ref is present.
+
+Tolerance: the 3-D path has no order-dependent reduction, and the restatement
+keeps the reference's operand order, so 3-D results are required to be
+BIT-IDENTICAL.  The 2-D all-Neumann path subtracts a mean whose summation
+order is unspecified in the reference (OpenMP reduction,
+ndsm_multigrid_core.f90:1214): 1e-14 absolute there.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from golden_inputs import (BCS3, KERNEL_SHAPES_2D, KERNEL_SHAPES_3D, analytic_case, manufactured_poisson,
+                           rand_field, uniform_mesh)
+
+
+def _tag(ns):
+    return "x".join(str(n) for n in ns)
+
+
+@pytest.mark.parametrize("ns", KERNEL_SHAPES_3D, ids=_tag)
+def test_kernels3d_golden(port, golden_dir, ns):
+    g = np.load(os.path.join(golden_dir, f"kernels3d_{_tag(ns)}.npz"))
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
+    shapes, meshes = port.hierarchy(ns, mesh)
+    assert np.array_equal(shapes, g["level_shapes"])
+    for l, lv in enumerate(meshes):
+        for d, m in enumerate(lv):
+            assert np.array_equal(m, g[f"mesh_l{l+1}_d{d+1}"])
+    for bcs in BCS3:
+        assert np.array_equal(port.relax3d(u, rhs, mesh, bcs), g[f"relax_{bcs}"])
+        assert np.array_equal(port.residual3d(u, rhs, mesh, bcs), g[f"residual_{bcs}"])
+        assert np.array_equal(port.vcycle(u, rhs, mesh, bcs), g[f"vcycle_{bcs}"])
+    for lvl in range(1, len(shapes)):
+        f = rand_field(tuple(int(v) for v in shapes[lvl - 1][::-1]), 3000 + lvl)
+        c = rand_field(tuple(int(v) for v in shapes[lvl][::-1]), 4000 + lvl)
+        assert np.array_equal(port.restrict(f, ns, mesh, lvl), g[f"restrict_l{lvl}"])
+        assert np.array_equal(port.interp(c, ns, mesh, lvl), g[f"interp_l{lvl}"])
+    un = u.copy()
+    assert np.array_equal(np.array(port.update_u(rhs, un)), g["update_u"])
+    assert np.array_equal(un, rhs)
+
+
+@pytest.mark.parametrize("ns", KERNEL_SHAPES_2D, ids=_tag)
+def test_kernels2d_golden(port, golden_dir, ns):
+    g = np.load(os.path.join(golden_dir, f"kernels2d_{_tag(ns)}.npz"))
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
+    rhs0 = rhs - rhs.mean()
+    shapes, _ = port.hierarchy(ns, mesh)
+    assert np.array_equal(shapes, g["level_shapes"])
+    for bcs in ("NNNN", "DNND"):
+        np.testing.assert_allclose(port.relax_nd(u, rhs, mesh, bcs), g[f"relax_{bcs}"], rtol=0, atol=1e-14)
+        assert np.array_equal(port.residual_nd(u, rhs, mesh, bcs), g[f"residual_{bcs}"])
+    np.testing.assert_allclose(port.vcycle(u, rhs0, mesh, "NNNN"), g["vcycle_NNNN"], rtol=0, atol=1e-14)
+    ierr, us, du, hist, nc, sw = port.solve_bvp(np.zeros(shp), rhs0, mesh, "NNNN", hist_len=64)
+    assert ierr == int(g["solve_NNNN_meta"][0])
+    np.testing.assert_allclose(us, g["solve_NNNN"], rtol=0, atol=1e-13)
+    for lvl in range(1, len(shapes)):
+        f = rand_field(tuple(int(v) for v in shapes[lvl - 1][::-1]), 3000 + lvl)
+        c = rand_field(tuple(int(v) for v in shapes[lvl][::-1]), 4000 + lvl)
+        assert np.array_equal(port.restrict(f, ns, mesh, lvl), g[f"restrict_l{lvl}"])
+        assert np.array_equal(port.interp(c, ns, mesh, lvl), g[f"interp_l{lvl}"])
+
+
+@pytest.mark.parametrize("ns", ([22, 22, 22], [33, 22, 27], [64, 64, 64]), ids=_tag)
+@pytest.mark.parametrize("bcs", BCS3)
+def test_solve3d_history_golden(port, golden_dir, ns, bcs):
+    hist_all = json.load(open(os.path.join(golden_dir, "solve3d_history.json")))
+    h = hist_all[f"{_tag(ns)}_{bcs}"]
+    mesh = uniform_mesh(ns)
+    us, rhs = manufactured_poisson(mesh, bcs)
+    ierr, u, du, hist, nc, sw = port.solve_bvp(np.zeros_like(us), rhs, mesh, bcs, hist_len=64)
+    assert ierr == 0 and nc == h["ncycles"]
+    assert list(hist) == h["du"]          # bit-identical residual history
+    assert du == h["du"][-1]
+    if ns[0] <= 33:
+        assert np.array_equal(u, np.load(os.path.join(golden_dir, f"solve3d_{_tag(ns)}_{bcs}.npy")))
+    else:
+        p = np.load(os.path.join(golden_dir, f"solve3d_{_tag(ns)}_{bcs}_planes.npz"))
+        assert np.array_equal(u[ns[2] // 2], p["kz"])
+        assert np.array_equal(u[:, ns[1] // 2], p["jy"])
+        assert np.array_equal(u[:, :, ns[0] // 2], p["ix"])
+    # second-order truncation error of the discretisation, not of the solver
+    assert abs(np.abs(u - us).max() - h["err_vs_exact"]) < 1e-15
+
+
+# tests/integration_test/results_test1.txt:6-7 (dx, Ea_max, Ea_avg, Eb_max, Eb_avg)
+RESULTS_TEST1 = {
+    22: ("4.76190e-02", "1.86048e-03", "2.67773e-04", "7.65805e-02", "6.53421e-03"),
+    44: ("2.32558e-02", "4.44560e-04", "6.18187e-05", "1.95261e-02", "1.35063e-03"),
+}
+
+
+@pytest.mark.parametrize("n", (22, 44))
+def test_pipeline_known_answer_rows(port, n):
+    x, y, z, A1, b1 = analytic_case(n)
+    ierr, A, B, ioptc, ropt = port.vector_potential(x, y, z, b1)
+    assert ierr == 0
+    eA = np.linalg.norm(A1 - A, axis=0)
+    eB = np.linalg.norm(b1 - B, axis=0)
+    got = tuple("{:.5e}".format(v) for v in (x[1] - x[0], eA.max(), eA.mean(), eB.max(), eB.mean()))
+    assert got == RESULTS_TEST1[n]
+
+
+@pytest.mark.parametrize("name,ns", (("pipeline_22", 22), ("pipeline_33x22x27", [33, 22, 27])))
+def test_pipeline_golden(port, golden_dir, name, ns):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    x, y, z, A1, b1 = analytic_case(ns)
+    ierr, A, B, ioptc, ropt = port.vector_potential(x, y, z, b1)
+    assert ierr == 0 and np.array_equal(ioptc, g["ioptc"])
+    # 2-D face solves carry the unordered mean reduction -> not bitwise
+    assert np.abs(A - g["A"]).max() <= 1e-12 * np.abs(g["A"]).max()
+    h = x[1] - x[0]
+    assert np.abs(B - g["B"]).max() <= 1e-12 * np.abs(g["A"]).max() / h * 4
+
+
+def test_live_reference_random(port, ref):
+    """(c): fresh inputs, the reference run live (container only)."""
+    rng = np.random.default_rng(12345)
+    for ns in ([17, 23, 19], [40, 24, 32]):
+        mesh = uniform_mesh(ns)
+        shp = tuple(ns[::-1])
+        u, rhs = rng.uniform(-1, 1, shp), rng.uniform(-1, 1, shp)
+        for bcs in BCS3 + ("NNNNNN", "DDDDDD", "NDNDND"):
+            a, b = port.relax3d(u, rhs, mesh, bcs), ref.relax3d(u, rhs, mesh, bcs)
+            if bcs == "NNNNNN":
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-14)
+            else:
+                assert np.array_equal(a, b)
+            assert np.array_equal(port.residual3d(u, rhs, mesh, bcs), ref.residual3d(u, rhs, mesh, bcs))
+        assert np.array_equal(port.vcycle(u, rhs, mesh, "DNDDND", ms=3), ref.vcycle(u, rhs, mesh, "DNDDND", ms=3))
