@@ -1,0 +1,117 @@
+/* Device layer of libndsm_hip: runtime + HIP kernel launchers (gfx950).
+ *
+ * This is the *internal* C interface between the Fortran 2003 host driver
+ * (ndsm_amd/fsrc, bound through ISO_C_BINDING in ndsmh_iface.f90) and the
+ * hand-written HIP kernels.  The drop-in boundary a user binds against is
+ * include/ndsm_hip.h, not this file.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a non-zero HIP / NDSMK_E* code on
+ *     failure; ndsmk_last_error() gives the text.  Nothing falls back to the CPU.
+ *   - all kernels are enqueued on ONE library-owned HIP stream and return
+ *     immediately unless stated "blocking".
+ *   - arrays are Fortran order (x fastest); pointers are device pointers
+ *     unless prefixed h_.
+ *   - a level's geometry travels in ndsmk_grid (filled by the host driver with
+ *     the reference's arithmetic, ndsm_optimized.f90:68-94).
+ */
+#ifndef NDSM_KERNELS_H
+#define NDSM_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  NDSMK_OK = 0,
+  NDSMK_ENODEV = 9001,   /* no HIP device visible */
+  NDSMK_EARG = 9002,     /* shape/argument check failed on the host */
+  NDSMK_ENCCL = 9003     /* RCCL call failed */
+};
+
+/* geometry + operator constants of one grid level (interoperable with the
+ * Fortran TYPE, BIND(C) :: ndsmk_grid in ndsmh_iface.f90) */
+typedef struct {
+  int32_t ndim;          /* 2 or 3 */
+  int32_t n[3];          /* nx, ny, nz (nz = 1 in 2-D) */
+  int32_t lb[3], ub[3];  /* 0-based inclusive update bounds: shrink by one on 'D' faces */
+  int32_t first_par;     /* colour of the first half-sweep: (i+j+k)&1 == first_par */
+  int32_t all_neumann;   /* 1: subtract the mean after each sweep */
+  int32_t k0;            /* global z index of local plane 0 (z-slab runs), else 0 */
+  int32_t nzg;           /* global nz (== n[2] unless z-slab) */
+  double w[3];           /* 1/h^2 per dimension */
+  double w1;             /* 1 / (2 (wx+wy+wz)) */
+  double wc;             /* 2 (wx+wy+wz) */
+} ndsmk_grid;
+
+/* one inter-level transfer: 1-D tables per dimension, built on the host with
+ * the reference's arithmetic (ndsm_interp.f90:373-435, :141-142, :229-281) */
+typedef struct {
+  int32_t nf[3], nc[3];   /* fine / coarse shapes */
+  int32_t maxt[3];        /* taps reserved per coarse index and dim (row length of rw) */
+  /* prolongation: per fine index i of dim d */
+  const int32_t *plo[3];  /* lower bracket index into the coarse dim (0-based) */
+  const double *pwl[3];   /* weight of the UPPER bracket point  wl = (q-ql)/dq */
+  const double *pwh[3];   /* weight of the LOWER bracket point  wh = -(q-qh)/dq */
+  /* restriction: per coarse index I of dim d */
+  const int32_t *rlo[3];  /* first contributing fine index (0-based) */
+  const int32_t *rcnt[3]; /* number of contributing fine points */
+  const double *rw[3];    /* rw[d][I*maxt[d] + t] = c2 = |h_c - |q_f - q_c||  (ndsm_interp.f90:279-280) */
+  double w2[3];           /* h_f / h_c^2 per dimension (ndsm_interp.f90:229) */
+} ndsmk_xfer;
+
+/* ---- runtime ------------------------------------------------------- */
+int ndsmk_device_count(void);
+int ndsmk_init(int device);                 /* device < 0: LOCAL_RANK % count (else 0) */
+int ndsmk_shutdown(void);
+const char *ndsmk_last_error(void);
+int ndsmk_device_name(char *buf, int len);
+void *ndsmk_stream(void);                   /* the library's hipStream_t */
+
+int ndsmk_alloc(void **p, size_t bytes);
+int ndsmk_free(void *p);
+int ndsmk_h2d(void *dst, const void *h_src, size_t bytes);   /* blocking */
+int ndsmk_d2h(void *h_dst, const void *src, size_t bytes);   /* blocking */
+int ndsmk_d2d(void *dst, const void *src, size_t bytes);
+int ndsmk_fill0(void *p, size_t bytes);
+int ndsmk_sync(void);                                        /* blocking */
+int ndsmk_timer_start(void);                /* hipEventRecord on the library stream */
+int ndsmk_timer_stop(double *ms);           /* blocking; elapsed between start and now */
+
+/* ---- kernels ------------------------------------------------------- */
+/* nsweeps full red-black Gauss-Seidel sweeps (ndsm_optimized.f90:40-191 in
+ * 3-D, ndsm_poisson.f90:451-549 in 2-D incl. the all-Neumann mean shift).
+ * variant: 0 = pick the fastest valid kernel, 1 = two-pass colour kernels,
+ * 2 = fused z-streaming kernel (3-D only). */
+int ndsmk_relax(const ndsmk_grid *g, double *u, const double *rhs, int nsweeps, int variant);
+/* r = rhs - L u, zero on Dirichlet faces (ndsm_optimized.f90:346-447 / ndsm_poisson.f90:280-353) */
+int ndsmk_residual(const ndsmk_grid *g, const double *u, const double *rhs, double *r);
+/* rhs_c = R r_f ; also u_c = 0 if u_c != NULL (ndsm_multigrid_core.f90:551,557-558) */
+int ndsmk_restrict(const ndsmk_xfer *x, const double *r_f, double *rhs_c, double *u_c);
+/* u_f += P u_c (ndsm_multigrid_core.f90:659,672) */
+int ndsmk_prolong_add(const ndsmk_xfer *x, const double *u_c, double *u_f);
+/* blocking: out[0] = max|a-b|, out[1] = sum|a-b| ; then b <- a if copy != 0
+ * (update_u, ndsm_multigrid_core.f90:1077-1122 ; du_metrics :808-853) */
+int ndsmk_diff_metrics(const double *a, double *b, int64_t n, int copy, double *h_out2);
+/* coarsest-grid "exact" solve (ndsm_multigrid_core.f90:728-800): repeat
+ * {test du <= ex_tol first; relax; du = max|.| or mean|.| of the change} at most
+ * nmax times.  d_info (DEVICE, 2 x int64) accumulates [0] sweeps done and
+ * [1] the number of solves that hit nmax unconverged; the call does not block
+ * for grids of <= 2048 points.  scratch: n doubles (device). */
+int ndsmk_solve_exact(const ndsmk_grid *g, double *u, const double *rhs, double *scratch,
+                      double ex_tol, int use_max, int nmax, int64_t *d_info);
+
+/* A += flux-balance fields, B = curl A (+ linear field when curl_first), all on
+ * device arrays (nx,ny,nz,3); x,y,z are DEVICE mesh vectors, h_* host scalars
+ * (ndsm_vector_potential.f90:453-477, :759-872, :880-950) */
+int ndsmk_balance_curl(double *A, double *B, const int32_t *n3, const double *x, const double *y,
+                       const double *z, const double *h_phi6, const double *h_span3,
+                       const double *h_dq3, int curl_first);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

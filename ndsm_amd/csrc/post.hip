@@ -1,0 +1,133 @@
+// Post-processing of the vector-potential driver on the device, so that A and
+// B never leave HBM between the last V-cycle and the single final download:
+//
+//   balance : analytic fields that carry the net flux through opposite faces,
+//             added to A and B              ndsm_vector_potential.f90:880-950
+//   curl    : B = curl A, second-order centred differences, 3-point one-sided
+//             on the end planes             ndsm_vector_potential.f90:759-872
+//
+// Pure streaming: balance touches 6 N-vectors (48 B/pt in, 48 B/pt out), curl
+// reads 3 and writes 3 (48 B/pt with neighbours served by L2).  Operand order
+// follows the reference; -ffp-contract=off keeps the roundings identical.
+#include "common.hpp"
+
+namespace {
+
+struct PostArgs {
+  int n[3];
+  const double *x, *y, *z;  // device mesh vectors
+  double phi[6];
+  double span[3];
+  double dq[3];
+};
+
+template <bool WITH_B>
+__global__ __launch_bounds__(256) void balance_k(double *__restrict__ A, double *__restrict__ B, PostArgs p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= p.n[0] || j >= p.n[1]) return;
+  const size_t N = (size_t)p.n[0] * p.n[1] * p.n[2];
+  const size_t c = (size_t)i + (size_t)p.n[0] * ((size_t)j + (size_t)p.n[1] * (size_t)k);
+  const double vol = p.span[0] * p.span[1] * p.span[2];
+  const double g1 = (p.phi[1] - p.phi[0]) / vol, g2 = (p.phi[3] - p.phi[2]) / vol, g3 = (p.phi[5] - p.phi[4]) / vol;
+  const double x = p.x[i], y = p.y[j], z = p.z[k];
+  const double third = 1.0 / 3.0;
+  // :927-929
+  const double b1 = g1 * x + p.phi[0] * p.span[0] / vol;
+  const double b2 = g2 * y + p.phi[2] * p.span[1] / vol;
+  const double b3 = g3 * z + p.phi[4] * p.span[2] / vol;
+  // :932-939  A1_l, A2_l, A3_l (linear-B part) and A_c (constant-B part)
+  const double l1x = -g3 * y * z, l1y = 0.0, l1z = +g1 * x * y;
+  const double l2x = +g2 * z * y, l2y = -g1 * x * z, l2z = 0.0;
+  const double l3x = 0.0, l3y = +g3 * x * z, l3z = -g2 * x * y;
+  const double cx = -(p.phi[4] * p.span[2] * y / vol);
+  const double cy = -(p.phi[0] * p.span[0] * z / vol);
+  const double cz = -(p.phi[2] * p.span[1] * x / vol);
+  // :942-943
+  if (WITH_B) {
+    B[c] = B[c] + b1;
+    B[c + N] = B[c + N] + b2;
+    B[c + 2 * N] = B[c + 2 * N] + b3;
+  }
+  A[c] = A[c] + cx + third * (l1x + l2x + l3x);
+  A[c + N] = A[c + N] + cy + third * (l1y + l2y + l3y);
+  A[c + 2 * N] = A[c + 2 * N] + cz + third * (l1z + l2z + l3z);
+}
+
+// d/dq along one axis at index q of n (stride s), derivq :852-870
+__device__ __forceinline__ double ddq(const double *__restrict__ v, size_t c, int q, int n, size_t s, double h) {
+  const double half = 0.5;
+  double d = 0.0;
+  if (q == 0) {
+    d = d + v[c] * (-3 * half / h);
+    d = d + v[c + s] * (+4 * half / h);
+    d = d + v[c + 2 * s] * (-1 * half / h);
+  } else if (q == n - 1) {
+    d = d + v[c] * (+3 * half / h);
+    d = d + v[c - s] * (-4 * half / h);
+    d = d + v[c - 2 * s] * (+1 * half / h);
+  } else {
+    d = d + v[c - s] * (-1 * half / h);
+    d = d + v[c + s] * (+1 * half / h);
+  }
+  return d;
+}
+
+__global__ __launch_bounds__(256) void curl_k(const double *__restrict__ A, double *__restrict__ B, PostArgs p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= p.n[0] || j >= p.n[1]) return;
+  const size_t sy = (size_t)p.n[0], sz = (size_t)p.n[0] * p.n[1];
+  const size_t N = sz * p.n[2];
+  const size_t c = (size_t)i + sy * (size_t)j + sz * (size_t)k;
+  const double *Ax = A, *Ay = A + N, *Az = A + 2 * N;
+  const double axy = ddq(Ax, c, j, p.n[1], sy, p.dq[1]);
+  const double axz = ddq(Ax, c, k, p.n[2], sz, p.dq[2]);
+  const double ayx = ddq(Ay, c, i, p.n[0], 1, p.dq[0]);
+  const double ayz = ddq(Ay, c, k, p.n[2], sz, p.dq[2]);
+  const double azx = ddq(Az, c, i, p.n[0], 1, p.dq[0]);
+  const double azy = ddq(Az, c, j, p.n[1], sy, p.dq[1]);
+  B[c] = azy - ayz;          // :802-804
+  B[c + N] = axz - azx;
+  B[c + 2 * N] = ayx - axy;
+}
+
+}  // namespace
+
+// A, B: device arrays (nx,ny,nz,3).  x,y,z: DEVICE mesh vectors.  curl_first
+// != 0 selects the reference's IOPT_FLXCRL == 1 order (:455-465).
+extern "C" int ndsmk_balance_curl(double *A, double *B, const int32_t *n3, const double *x, const double *y,
+                                  const double *z, const double *h_phi6, const double *h_span3,
+                                  const double *h_dq3, int curl_first) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(n3[0] >= 3 && n3[1] >= 3 && n3[2] >= 3);  // one-sided stencils need three points
+  PostArgs p;
+  for (int d = 0; d < 3; ++d) {
+    p.n[d] = n3[d];
+    p.span[d] = h_span3[d];
+    p.dq[d] = h_dq3[d];
+  }
+  for (int f = 0; f < 6; ++f) p.phi[f] = h_phi6[f];
+  p.x = x;
+  p.y = y;
+  p.z = z;
+  dim3 block(64, 4, 1);
+  dim3 grid((n3[0] + 63) / 64, (n3[1] + 3) / 4, n3[2]);
+  hipStream_t s = ndsm::stream();
+  if (curl_first) {
+    hipLaunchKernelGGL(curl_k, grid, block, 0, s, A, B, p);
+    NDSM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(balance_k<true>, grid, block, 0, s, A, B, p);
+    NDSM_LAUNCH_CHECK();
+  } else {
+    // the reference also adds the linear field to B here (:474), but its curl
+    // (:475) then overwrites all of B: that dead update is skipped
+    hipLaunchKernelGGL(balance_k<false>, grid, block, 0, s, A, B, p);
+    NDSM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(curl_k, grid, block, 0, s, A, B, p);
+    NDSM_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -1,0 +1,171 @@
+// Device runtime of libndsm_hip: device selection, the library stream, memory
+// and copies, events.  No CPU fallback exists anywhere in this library: if no
+// MI355X is visible ndsmk_init fails and every entry point above it reports
+// the error to the caller.
+#include "common.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+struct Runtime {
+  bool up = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  char err[512] = "no error";
+};
+
+Runtime g_rt;
+std::mutex g_mu;
+
+}  // namespace
+
+namespace ndsm {
+
+hipStream_t stream() { return g_rt.stream; }
+bool ready() { return g_rt.up; }
+
+int fail(int code, const char *what, const char *file, int line) {
+  const char *base = std::strrchr(file, '/');
+  std::snprintf(g_rt.err, sizeof(g_rt.err), "%s (code %d) at %s:%d", what, code, base ? base + 1 : file, line);
+  if (const char *v = std::getenv("NDSM_HIP_VERBOSE"))
+    if (v[0] == '1') std::fprintf(stderr, "ERROR(libndsm_hip):%s\n", g_rt.err);
+  return code ? code : NDSMK_EARG;
+}
+
+int not_ready(const char *file, int line) {
+  return fail(NDSMK_ENODEV, "HIP runtime not initialised (ndsmk_init failed or was not called)", file, line);
+}
+
+}  // namespace ndsm
+
+extern "C" {
+
+const char *ndsmk_last_error(void) { return g_rt.err; }
+
+int ndsmk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ndsmk_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_rt.up && (device < 0 || device == g_rt.device)) return 0;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return ndsm::fail(NDSMK_ENODEV, "no HIP device visible - libndsm_hip has no CPU path", __FILE__, __LINE__);
+  if (device < 0) {
+    const char *lr = std::getenv("LOCAL_RANK");
+    device = lr ? std::atoi(lr) % n : 0;
+  }
+  NDSM_CHECK_ARG(device < n);
+  if (g_rt.up) {  // re-target: drop the old stream
+    (void)hipStreamDestroy(g_rt.stream);
+    (void)hipEventDestroy(g_rt.ev0);
+    (void)hipEventDestroy(g_rt.ev1);
+    g_rt.up = false;
+  }
+  NDSM_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  NDSM_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return ndsm::fail(NDSMK_ENODEV, "device is not gfx950 (this library carries MI355X code objects only)", __FILE__, __LINE__);
+  NDSM_HIP(hipStreamCreateWithFlags(&g_rt.stream, hipStreamNonBlocking));
+  NDSM_HIP(hipEventCreate(&g_rt.ev0));
+  NDSM_HIP(hipEventCreate(&g_rt.ev1));
+  g_rt.device = device;
+  g_rt.up = true;
+  return 0;
+}
+
+int ndsmk_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_rt.up) return 0;
+  (void)hipStreamSynchronize(g_rt.stream);
+  (void)hipStreamDestroy(g_rt.stream);
+  (void)hipEventDestroy(g_rt.ev0);
+  (void)hipEventDestroy(g_rt.ev1);
+  g_rt = Runtime();
+  return 0;
+}
+
+int ndsmk_device_name(char *buf, int len) {
+  NDSM_REQUIRE_READY();
+  hipDeviceProp_t prop;
+  NDSM_HIP(hipGetDeviceProperties(&prop, g_rt.device));
+  std::snprintf(buf, (size_t)len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return 0;
+}
+
+void *ndsmk_stream(void) { return (void *)g_rt.stream; }
+
+int ndsmk_alloc(void **p, size_t bytes) {
+  NDSM_REQUIRE_READY();
+  *p = nullptr;
+  if (bytes == 0) bytes = 8;
+  NDSM_HIP(hipMalloc(p, bytes));
+  return 0;
+}
+
+int ndsmk_free(void *p) {
+  if (!p) return 0;
+  NDSM_REQUIRE_READY();
+  NDSM_HIP(hipStreamSynchronize(g_rt.stream));
+  NDSM_HIP(hipFree(p));
+  return 0;
+}
+
+int ndsmk_h2d(void *dst, const void *h_src, size_t bytes) {
+  NDSM_REQUIRE_READY();
+  NDSM_HIP(hipMemcpyAsync(dst, h_src, bytes, hipMemcpyHostToDevice, g_rt.stream));
+  NDSM_HIP(hipStreamSynchronize(g_rt.stream));
+  return 0;
+}
+
+int ndsmk_d2h(void *h_dst, const void *src, size_t bytes) {
+  NDSM_REQUIRE_READY();
+  NDSM_HIP(hipMemcpyAsync(h_dst, src, bytes, hipMemcpyDeviceToHost, g_rt.stream));
+  NDSM_HIP(hipStreamSynchronize(g_rt.stream));
+  return 0;
+}
+
+int ndsmk_d2d(void *dst, const void *src, size_t bytes) {
+  NDSM_REQUIRE_READY();
+  NDSM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_rt.stream));
+  return 0;
+}
+
+int ndsmk_fill0(void *p, size_t bytes) {
+  NDSM_REQUIRE_READY();
+  NDSM_HIP(hipMemsetAsync(p, 0, bytes, g_rt.stream));
+  return 0;
+}
+
+int ndsmk_sync(void) {
+  NDSM_REQUIRE_READY();
+  NDSM_HIP(hipStreamSynchronize(g_rt.stream));
+  return 0;
+}
+
+int ndsmk_timer_start(void) {
+  NDSM_REQUIRE_READY();
+  NDSM_HIP(hipEventRecord(g_rt.ev0, g_rt.stream));
+  return 0;
+}
+
+int ndsmk_timer_stop(double *ms) {
+  NDSM_REQUIRE_READY();
+  NDSM_HIP(hipEventRecord(g_rt.ev1, g_rt.stream));
+  NDSM_HIP(hipEventSynchronize(g_rt.ev1));
+  float f = 0;
+  NDSM_HIP(hipEventElapsedTime(&f, g_rt.ev0, g_rt.ev1));
+  *ms = (double)f;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// Inter-level transfer on NDSM's NON-NESTED hierarchy (coarse meshes span the
+// same extent with floor(n/2) points, so h_c/h_f = (n_f-1)/(n_c-1) != 2):
+//
+//   restriction  rhs_c = R r_f : adjoint of N-linear interpolation, 3-6 taps per
+//                dimension (ndsm_interp.f90:186-292, driven by
+//                ndsm_multigrid_core.f90:1010-1065)
+//   prolongation u_f += P u_c  : N-linear interpolation with per-point weights
+//                (ndsm_interp.f90:85-158, ndsm_multigrid_core.f90:865-921, :692-712)
+//
+// The bracket searches and weights are separable, so the host builds 1-D tables
+// per dimension ONCE per hierarchy with the reference's exact arithmetic
+// (fsrc/ndsmh_grid.f90) and the kernels only gather + multiply.  The products
+// and sums are formed in the reference's order (weight = ((((c2x w2x) c2y) w2y)
+// c2z) w2z, taps summed x-fastest; interpolation reduced z, then y, then x) so
+// both operators are bit-identical to the reference.
+//
+// Algorithmic traffic: restriction 9 B / fine point, prolong+correct 17 B / fine point.
+#include "common.hpp"
+
+namespace {
+
+struct XferDev {  // by-value kernel argument (pointers are device pointers)
+  int nf[3], nc[3], maxt[3];
+  const int32_t *plo[3];
+  const double *pwl[3], *pwh[3];
+  const int32_t *rlo[3], *rcnt[3];
+  const double *rw[3];
+  double w2[3];
+};
+
+template <int NDIM>
+__global__ __launch_bounds__(256) void restrict_k(const double *__restrict__ f, double *__restrict__ rhs_c,
+                                                  double *__restrict__ u_c, XferDev x) {
+  const int I = blockIdx.x * blockDim.x + threadIdx.x;
+  const int J = blockIdx.y * blockDim.y + threadIdx.y;
+  const int K = blockIdx.z;
+  if (I >= x.nc[0] || J >= x.nc[1]) return;
+  const int i0 = x.rlo[0][I], ni = x.rcnt[0][I];
+  const int j0 = x.rlo[1][J], nj = x.rcnt[1][J];
+  const double *cx = x.rw[0] + (size_t)I * x.maxt[0];
+  const double *cy = x.rw[1] + (size_t)J * x.maxt[1];
+  const size_t sy = (size_t)x.nf[0], sz = (size_t)x.nf[0] * (size_t)x.nf[1];
+  double fc = 0.0;
+  if (NDIM == 3) {
+    const int k0 = x.rlo[2][K], nk = x.rcnt[2][K];
+    const double *cz = x.rw[2] + (size_t)K * x.maxt[2];
+    for (int kk = 0; kk < nk; ++kk) {
+      const double c2z = cz[kk];
+      for (int jj = 0; jj < nj; ++jj) {
+        const double c2y = cy[jj];
+        const double *row = f + (size_t)i0 + sy * (size_t)(j0 + jj) + sz * (size_t)(k0 + kk);
+        for (int ii = 0; ii < ni; ++ii) {
+          double w = cx[ii] * x.w2[0];  // 1 * c2 * w2 (ndsm_interp.f90:277-282)
+          w = w * c2y * x.w2[1];
+          w = w * c2z * x.w2[2];
+          fc = fc + w * row[ii];
+        }
+      }
+    }
+  } else {
+    for (int jj = 0; jj < nj; ++jj) {
+      const double c2y = cy[jj];
+      const double *row = f + (size_t)i0 + sy * (size_t)(j0 + jj);
+      for (int ii = 0; ii < ni; ++ii) {
+        double w = cx[ii] * x.w2[0];
+        w = w * c2y * x.w2[1];
+        fc = fc + w * row[ii];
+      }
+    }
+  }
+  const size_t c = (size_t)I + (size_t)x.nc[0] * ((size_t)J + (size_t)x.nc[1] * (size_t)K);
+  rhs_c[c] = fc;
+  if (u_c) u_c[c] = 0.0;  // coarse correction starts from zero (ndsm_multigrid_core.f90:557-558)
+}
+
+template <int NDIM>
+__global__ __launch_bounds__(256) void prolong_add_k(const double *__restrict__ uc, double *__restrict__ uf,
+                                                     XferDev x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= x.nf[0] || j >= x.nf[1]) return;
+  const int il = x.plo[0][i], jl = x.plo[1][j];
+  const double wlx = x.pwl[0][i], whx = x.pwh[0][i];
+  const double wly = x.pwl[1][j], why = x.pwh[1][j];
+  const size_t sy = (size_t)x.nc[0], sz = (size_t)x.nc[0] * (size_t)x.nc[1];
+  double v;
+  if (NDIM == 3) {
+    const int kl = x.plo[2][k];
+    const double wlz = x.pwl[2][k], whz = x.pwh[2][k];
+    const double *p = uc + (size_t)il + sy * (size_t)jl + sz * (size_t)kl;
+    // fs(n): bit0 = upper x, bit1 = upper y, bit2 = upper z (ndsm_interp.f90:340-363)
+    double f0 = p[0], f1 = p[1], f2 = p[sy], f3 = p[sy + 1];
+    double f4 = p[sz], f5 = p[sz + 1], f6 = p[sz + sy], f7 = p[sz + sy + 1];
+    f0 = whz * f0 + wlz * f4;  // last dimension first (ndsm_interp.f90:128-154)
+    f1 = whz * f1 + wlz * f5;
+    f2 = whz * f2 + wlz * f6;
+    f3 = whz * f3 + wlz * f7;
+    f0 = why * f0 + wly * f2;
+    f1 = why * f1 + wly * f3;
+    v = whx * f0 + wlx * f1;
+  } else {
+    const double *p = uc + (size_t)il + sy * (size_t)jl;
+    double f0 = p[0], f1 = p[1], f2 = p[sy], f3 = p[sy + 1];
+    f0 = why * f0 + wly * f2;
+    f1 = why * f1 + wly * f3;
+    v = whx * f0 + wlx * f1;
+  }
+  const size_t c = (size_t)i + (size_t)x.nf[0] * ((size_t)j + (size_t)x.nf[1] * (size_t)k);
+  uf[c] = uf[c] + v;
+}
+
+int to_dev(const ndsmk_xfer *x, XferDev *d, int *ndim) {
+  *ndim = (x->nf[2] == 1 && x->nc[2] == 1) ? 2 : 3;
+  for (int a = 0; a < 3; ++a) {
+    d->nf[a] = x->nf[a];
+    d->nc[a] = x->nc[a];
+    d->maxt[a] = x->maxt[a];
+    d->plo[a] = x->plo[a];
+    d->pwl[a] = x->pwl[a];
+    d->pwh[a] = x->pwh[a];
+    d->rlo[a] = x->rlo[a];
+    d->rcnt[a] = x->rcnt[a];
+    d->rw[a] = x->rw[a];
+    d->w2[a] = x->w2[a];
+  }
+  for (int a = 0; a < *ndim; ++a) {
+    NDSM_CHECK_ARG(x->nf[a] >= 2 && x->nc[a] >= 2 && x->maxt[a] >= 1);
+    NDSM_CHECK_ARG(x->plo[a] && x->pwl[a] && x->pwh[a] && x->rlo[a] && x->rcnt[a] && x->rw[a]);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ndsmk_restrict(const ndsmk_xfer *x, const double *r_f, double *rhs_c, double *u_c) {
+  NDSM_REQUIRE_READY();
+  XferDev d;
+  int ndim;
+  if (int rc = to_dev(x, &d, &ndim)) return rc;
+  dim3 block(32, 8, 1);
+  dim3 grid((d.nc[0] + 31) / 32, (d.nc[1] + 7) / 8, d.nc[2]);
+  if (ndim == 3)
+    hipLaunchKernelGGL(restrict_k<3>, grid, block, 0, ndsm::stream(), r_f, rhs_c, u_c, d);
+  else
+    hipLaunchKernelGGL(restrict_k<2>, grid, block, 0, ndsm::stream(), r_f, rhs_c, u_c, d);
+  NDSM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ndsmk_prolong_add(const ndsmk_xfer *x, const double *u_c, double *u_f) {
+  NDSM_REQUIRE_READY();
+  XferDev d;
+  int ndim;
+  if (int rc = to_dev(x, &d, &ndim)) return rc;
+  dim3 block(64, 4, 1);
+  dim3 grid((d.nf[0] + 63) / 64, (d.nf[1] + 3) / 4, d.nf[2]);
+  if (ndim == 3)
+    hipLaunchKernelGGL(prolong_add_k<3>, grid, block, 0, ndsm::stream(), u_c, u_f, d);
+  else
+    hipLaunchKernelGGL(prolong_add_k<2>, grid, block, 0, ndsm::stream(), u_c, u_f, d);
+  NDSM_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,452 @@
+! libndsm_hip - the C ABI (declared in include/ndsm_hip.h).
+!
+! Part 1 is the reference's complete dynamic symbol set, same names, same
+! argument lists, same option-slot values: ndsm_python_wrapper.f90:56-158
+! (ndsm_vector_solve) and :164-234 (twelve getters) - an unmodified ndsm.py
+! (ndsm.py:136-207) can load this library in place of ndsmf.so.
+! Part 2 is additive: a scalar Poisson entry and a persistent, device-resident
+! solver handle (SURVEY 8b "additive exports", 8f-4).  Nothing in part 1 changes
+! meaning because of part 2.
+!
+! Error behaviour: the reference returns 0/1 and STOPs the process on internal
+! asserts.  Here nothing STOPs: device/runtime failures come back as return
+! codes >= 9001 (ndsm_kernels.h) with the text on stderr and in
+! ndsm_hip_last_error().  There is no CPU fallback.
+module ndsmh_cabi
+
+  use, intrinsic :: iso_c_binding
+  use, intrinsic :: iso_fortran_env, only: error_unit
+  use ndsmh_iface
+  use ndsmh_mg
+  use ndsmh_vecpot
+  implicit none
+  private
+
+  interface
+    function c_strlen(s) bind(c, name="strlen") result(n)
+      import :: c_ptr, c_size_t
+      type(c_ptr), value :: s
+      integer(c_size_t) :: n
+    end function
+  end interface
+
+contains
+
+  ! wall clock in seconds (the reference uses OMP_GET_WTIME, ndsm_root.f90:521-536)
+  function wall_seconds() result(t)
+    real(c_double) :: t
+    integer(c_int64_t) :: cnt, rate
+    call system_clock(cnt, rate)
+    t = real(cnt, c_double) / real(rate, c_double)
+  end function
+
+  subroutine report(where, rc)
+    character(len=*), intent(in) :: where
+    integer(c_int), intent(in) :: rc
+    character(len=512) :: msg
+    call fetch_error(msg)
+    write (error_unit, '(A,I0)') "ERROR("//where//"):"//trim(msg)//":", rc
+  end subroutine
+
+  subroutine fetch_error(msg)
+    character(len=*), intent(out) :: msg
+    type(c_ptr) :: p
+    character(kind=c_char), pointer :: cs(:)
+    integer :: i, n
+    msg = ""
+    p = ndsmk_last_error()
+    if (.not. c_associated(p)) return
+    n = min(int(c_strlen(p)), len(msg))
+    call c_f_pointer(p, cs, [n])
+    do i = 1, n
+      msg(i:i) = cs(i)
+    end do
+  end subroutine
+
+  ! =====================================================================
+  ! Part 1 - the reference's symbols
+  ! =====================================================================
+
+  ! ndsm_python_wrapper.f90:56-79.  nshape4 = [nx,ny,nz,3]; A: in = initial
+  ! guess, out = vector potential; B: in = field whose normal boundary
+  ! component is read, out = curl A (+ flux balance).
+  function ndsm_vector_solve(nsize, nshape4, ioptc, ropt, x, y, z, A, B) bind(c, name="ndsm_vector_solve") &
+      result(ierr)
+    integer(c_size_t), value :: nsize
+    integer(c_int), intent(in) :: nshape4(4)
+    integer(c_int), intent(inout) :: ioptc(0:OPT_LEN - 1)
+    real(c_double), intent(inout) :: ropt(0:OPT_LEN - 1)
+    real(c_double), intent(in) :: x(nshape4(1)), y(nshape4(2)), z(nshape4(3))
+    real(c_double), intent(inout), target :: A(nsize), B(nsize)
+    integer(c_int) :: ierr
+    integer(ik) :: iopt(0:OPT_LEN - 1)
+    integer(c_int32_t) :: n3(3)
+    real(c_double) :: t0
+    real(c_double), pointer, contiguous :: A4(:, :, :, :), B4(:, :, :, :)
+    integer(c_int) :: rc
+
+    iopt = ioptc
+    verbose = (iopt(IOPT_DEBUG) == 1)
+    t0 = wall_seconds()
+    n3 = nshape4(1:3)
+    if (nshape4(4) /= 3 .or. int(nsize, ik) /= 3_ik * product(int(n3, ik))) then
+      ioptc(IOPT_IERR) = 1
+      ierr = 1
+      return
+    end if
+    A4(1:n3(1), 1:n3(2), 1:n3(3), 1:3) => A
+    B4(1:n3(1), 1:n3(2), 1:n3(3), 1:3) => B
+
+    rc = vecpot_solve(n3, iopt, ropt, x, y, z, A4, B4)
+
+    ropt(ROPT_TIM) = wall_seconds() - t0
+    ioptc = int(iopt, c_int)
+    if (rc /= 0) then
+      call report("ndsm_vector_solve", rc)
+      ioptc(IOPT_IERR) = rc
+      ierr = rc
+    else
+      ierr = int(iopt(IOPT_IERR), c_int)
+    end if
+  end function
+
+  ! ndsm_python_wrapper.f90:164-234 - slot indices, discovered at run time by ndsm.py:155-174
+  function get_iopt_len() bind(c, name="get_iopt_len") result(v)
+    integer(c_int) :: v
+    v = OPT_LEN
+  end function
+  function get_iopt_ierr() bind(c, name="get_iopt_ierr") result(v)
+    integer(c_int) :: v
+    v = OPT_LEN            ! sic: the reference returns IOPT_LEN here (:170-174, quirk Q5)
+  end function
+  function get_iopt_ms() bind(c, name="get_iopt_ms") result(v)
+    integer(c_int) :: v
+    v = IOPT_MS
+  end function
+  function get_iopt_ncycles() bind(c, name="get_iopt_ncycles") result(v)
+    integer(c_int) :: v
+    v = IOPT_NCYCLES
+  end function
+  function get_iopt_debug() bind(c, name="get_iopt_debug") result(v)
+    integer(c_int) :: v
+    v = IOPT_DEBUG
+  end function
+  function get_iopt_dumax() bind(c, name="get_iopt_dumax") result(v)
+    integer(c_int) :: v
+    v = IOPT_DUMAX
+  end function
+  function get_iopt_iopt_nmaxex() bind(c, name="get_iopt_iopt_nmaxex") result(v)
+    integer(c_int) :: v
+    v = IOPT_NMAXEX
+  end function
+  function get_iopt_true() bind(c, name="get_iopt_true") result(v)
+    integer(c_int) :: v
+    v = 1
+  end function
+  function get_iopt_false() bind(c, name="get_iopt_false") result(v)
+    integer(c_int) :: v
+    v = 0
+  end function
+  function get_ropt_tim() bind(c, name="get_ropt_tim") result(v)
+    integer(c_int) :: v
+    v = ROPT_TIM
+  end function
+  function get_ropt_vtol() bind(c, name="get_ropt_vtol") result(v)
+    integer(c_int) :: v
+    v = ROPT_VTOL
+  end function
+  function get_ropt_ctol() bind(c, name="get_ropt_ctol") result(v)
+    integer(c_int) :: v
+    v = ROPT_CTOL
+  end function
+
+  ! =====================================================================
+  ! Part 2 - additive exports
+  ! =====================================================================
+
+  function get_iopt_fail3d() bind(c, name="get_iopt_fail3d") result(v)
+    integer(c_int) :: v
+    v = IOPT_FAIL3D
+  end function
+  function get_iopt_ngrids() bind(c, name="get_iopt_ngrids") result(v)
+    integer(c_int) :: v
+    v = IOPT_NGRIDS
+  end function
+  function get_iopt_ncyc_out() bind(c, name="get_iopt_ncyc_out") result(v)
+    integer(c_int) :: v
+    v = IOPT_NCYC_OUT
+  end function
+  function get_ropt_dulast() bind(c, name="get_ropt_dulast") result(v)
+    integer(c_int) :: v
+    v = ROPT_DULAST
+  end function
+
+  function ndsm_hip_device_count() bind(c, name="ndsm_hip_device_count") result(n)
+    integer(c_int) :: n
+    n = ndsmk_device_count()
+  end function
+
+  function ndsm_hip_init(device) bind(c, name="ndsm_hip_init") result(rc)
+    integer(c_int), value :: device
+    integer(c_int) :: rc
+    rc = ndsmk_init(device)
+  end function
+
+  subroutine ndsm_hip_last_error(buf, n) bind(c, name="ndsm_hip_last_error")
+    integer(c_int), value :: n
+    character(kind=c_char), intent(out) :: buf(n)
+    character(len=512) :: msg
+    integer :: i, m
+    call fetch_error(msg)
+    m = min(len_trim(msg), n - 1)
+    do i = 1, m
+      buf(i) = msg(i:i)
+    end do
+    buf(m + 1) = c_null_char
+  end subroutine
+
+  function ndsm_hip_sync() bind(c, name="ndsm_hip_sync") result(rc)
+    integer(c_int) :: rc
+    rc = ndsmk_sync()
+  end function
+  function ndsm_hip_timer_start() bind(c, name="ndsm_hip_timer_start") result(rc)
+    integer(c_int) :: rc
+    rc = ndsmk_timer_start()
+  end function
+  function ndsm_hip_timer_stop(ms) bind(c, name="ndsm_hip_timer_stop") result(rc)
+    real(c_double), intent(out) :: ms
+    integer(c_int) :: rc
+    rc = ndsmk_timer_stop(ms)
+  end function
+
+  ! Scalar Poisson problem laplace(u) = rhs, host buffers.  bcs = 2*ndim
+  ! letters (lower faces, then upper faces).  Options in the same slots as
+  ! ndsm_vector_solve; rhs may be NULL (zero); hist may be NULL.
+  function ndsm_hip_poisson_solve(ndim, nshape, x, y, z, bcs, ioptc, ropt, u, rhs, hist, hist_len) &
+      bind(c, name="ndsm_hip_poisson_solve") result(ierr)
+    integer(c_int), value :: ndim, hist_len
+    integer(c_int), intent(in) :: nshape(ndim)
+    type(c_ptr), value :: x, y, z, u, rhs, hist
+    character(kind=c_char), intent(in) :: bcs(2 * ndim)
+    integer(c_int), intent(inout) :: ioptc(0:OPT_LEN - 1)
+    real(c_double), intent(inout) :: ropt(0:OPT_LEN - 1)
+    integer(c_int) :: ierr
+    integer(c_int32_t) :: n3(3)
+    real(c_double), pointer :: qx(:), qy(:), qz(:), hh(:)
+    real(c_double), target :: dummy(2)
+    character(len=1) :: bc(6)
+    real(c_double) :: du_last, t0
+    integer :: ncyc, ie, d
+    integer(c_int) :: rc
+
+    ierr = NDSMK_EARG
+    if (ndim /= 2 .and. ndim /= 3) return
+    t0 = wall_seconds()
+    n3 = 1
+    n3(1:ndim) = nshape(1:ndim)
+    dummy = [0.0_wp, 1.0_wp]
+    call c_f_pointer(x, qx, [n3(1)])
+    call c_f_pointer(y, qy, [n3(2)])
+    if (ndim == 3) then
+      call c_f_pointer(z, qz, [n3(3)])
+    else
+      qz => dummy
+    end if
+    bc = 'N'
+    do d = 1, 2 * ndim
+      bc(d) = bcs(d)
+    end do
+    verbose = (ioptc(IOPT_DEBUG) == 1)
+    if (c_associated(hist) .and. hist_len > 0) then
+      call c_f_pointer(hist, hh, [hist_len])
+      rc = poisson_solve(int(ndim), n3, qx, qy, qz, bc, int(ioptc(IOPT_MS)), ropt(ROPT_CTOL), &
+                         ioptc(IOPT_DUMAX) == 1, int(ioptc(IOPT_NMAXEX)), int(ioptc(IOPT_NGRIDS)), &
+                         ropt(ROPT_VTOL), int(ioptc(IOPT_NCYCLES)), u, rhs, du_last, ncyc, ie, hh)
+    else
+      rc = poisson_solve(int(ndim), n3, qx, qy, qz, bc, int(ioptc(IOPT_MS)), ropt(ROPT_CTOL), &
+                         ioptc(IOPT_DUMAX) == 1, int(ioptc(IOPT_NMAXEX)), int(ioptc(IOPT_NGRIDS)), &
+                         ropt(ROPT_VTOL), int(ioptc(IOPT_NCYCLES)), u, rhs, du_last, ncyc, ie)
+    end if
+    ropt(ROPT_TIM) = wall_seconds() - t0
+    if (rc /= 0) then
+      call report("ndsm_hip_poisson_solve", rc)
+      ierr = rc
+      return
+    end if
+    ioptc(IOPT_IERR) = ie
+    ioptc(IOPT_NCYC_OUT) = ncyc
+    ropt(ROPT_DULAST) = du_last
+    ierr = ie
+  end function
+
+  ! ---- persistent device-resident solver ------------------------------
+
+  function ndsm_hip_mg_create(ndim, nshape, x, y, z, bcs, ngrids, ms, ex_tol, du_max, nmax_exact, handle) &
+      bind(c, name="ndsm_hip_mg_create") result(rc)
+    integer(c_int), value :: ndim, ngrids, ms, du_max, nmax_exact
+    real(c_double), value :: ex_tol
+    integer(c_int), intent(in) :: nshape(ndim)
+    type(c_ptr), value :: x, y, z
+    character(kind=c_char), intent(in) :: bcs(2 * ndim)
+    type(c_ptr), intent(out) :: handle
+    integer(c_int) :: rc
+    type(mg_solver), pointer :: s
+    integer(c_int32_t) :: n3(3)
+    real(c_double), pointer :: qx(:), qy(:), qz(:)
+    real(c_double), target :: dummy(2)
+    character(len=1) :: bc(6)
+    integer :: d
+
+    handle = c_null_ptr
+    rc = NDSMK_EARG
+    if (ndim /= 2 .and. ndim /= 3) return
+    n3 = 1
+    n3(1:ndim) = nshape(1:ndim)
+    dummy = [0.0_wp, 1.0_wp]
+    call c_f_pointer(x, qx, [n3(1)])
+    call c_f_pointer(y, qy, [n3(2)])
+    if (ndim == 3) then
+      call c_f_pointer(z, qz, [n3(3)])
+    else
+      qz => dummy
+    end if
+    bc = 'N'
+    do d = 1, 2 * ndim
+      bc(d) = bcs(d)
+    end do
+    allocate (s)
+    rc = mg_create(s, int(ndim), n3, qx, qy, qz, bc, int(ngrids))
+    if (rc /= 0) then
+      call mg_destroy(s)
+      deallocate (s)
+      return
+    end if
+    s%ms = ms; s%ex_tol = ex_tol; s%use_max = (du_max == 1); s%nmax_exact = nmax_exact
+    handle = c_loc(s)
+  end function
+
+  function ndsm_hip_mg_destroy(handle) bind(c, name="ndsm_hip_mg_destroy") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int) :: rc
+    type(mg_solver), pointer :: s
+    rc = 0
+    if (.not. c_associated(handle)) return
+    call c_f_pointer(handle, s)
+    call mg_destroy(s)
+    deallocate (s)
+  end function
+
+  ! shapes(3, ngrids) in Fortran order; pass ngrids_cap = room in `shapes`
+  function ndsm_hip_mg_levels(handle, ngrids_cap, shapes) bind(c, name="ndsm_hip_mg_levels") result(ng)
+    type(c_ptr), value :: handle
+    integer(c_int), value :: ngrids_cap
+    integer(c_int), intent(out) :: shapes(3, ngrids_cap)
+    integer(c_int) :: ng
+    type(mg_solver), pointer :: s
+    integer :: l
+    call c_f_pointer(handle, s)
+    ng = s%ngrids
+    do l = 1, min(s%ngrids, int(ngrids_cap))
+      shapes(:, l) = s%lev(l)%n
+    end do
+  end function
+
+  function ndsm_hip_mg_set_ms(handle, ms) bind(c, name="ndsm_hip_mg_set_ms") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int), value :: ms
+    integer(c_int) :: rc
+    type(mg_solver), pointer :: s
+    call c_f_pointer(handle, s)
+    s%ms = ms
+    rc = 0
+  end function
+
+  ! which: 0 = u, 1 = rhs, 2 = residual scratch (level-1 sized, valid after op RESIDUAL)
+  function ndsm_hip_mg_upload(handle, level, which, host) bind(c, name="ndsm_hip_mg_upload") result(rc)
+    type(c_ptr), value :: handle, host
+    integer(c_int), value :: level, which
+    integer(c_int) :: rc
+    type(mg_solver), pointer :: s
+    type(c_ptr) :: d
+    integer(ik) :: n
+    call c_f_pointer(handle, s)
+    d = mg_level_ptr(s, int(level), int(which), n)
+    rc = NDSMK_EARG
+    if (.not. c_associated(d)) return
+    rc = ndsmk_h2d(d, host, int(n, c_size_t) * 8_c_size_t)
+  end function
+
+  function ndsm_hip_mg_download(handle, level, which, host) bind(c, name="ndsm_hip_mg_download") result(rc)
+    type(c_ptr), value :: handle, host
+    integer(c_int), value :: level, which
+    integer(c_int) :: rc
+    type(mg_solver), pointer :: s
+    type(c_ptr) :: d
+    integer(ik) :: n
+    call c_f_pointer(handle, s)
+    d = mg_level_ptr(s, int(level), int(which), n)
+    rc = NDSMK_EARG
+    if (.not. c_associated(d)) return
+    rc = ndsmk_d2h(host, d, int(n, c_size_t) * 8_c_size_t)
+  end function
+
+  ! op: 0 relax(count sweeps) 1 residual 2 restrict(level->level+1) 3 prolong-add
+  ! (level+1->level) 4 coarsest solve 5 relax via colour kernels 6 relax via fused kernel
+  function ndsm_hip_mg_op(handle, op, level, count) bind(c, name="ndsm_hip_mg_op") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int), value :: op, level, count
+    integer(c_int) :: rc
+    type(mg_solver), pointer :: s
+    call c_f_pointer(handle, s)
+    rc = mg_op(s, int(op), int(level), int(count))
+  end function
+
+  ! enqueue ncycles V-cycles; returns without waiting for the GPU
+  function ndsm_hip_mg_vcycle(handle, ncycles) bind(c, name="ndsm_hip_mg_vcycle") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int), value :: ncycles
+    integer(c_int) :: rc
+    type(mg_solver), pointer :: s
+    integer :: i
+    call c_f_pointer(handle, s)
+    rc = 0
+    do i = 1, ncycles
+      rc = mg_vcycle(s)
+      if (rc /= 0) return
+    end do
+  end function
+
+  ! V-cycles to vc_tol on the resident problem: 0 converged, 1 not, >= 9001 error
+  function ndsm_hip_mg_solve(handle, vc_tol, nmax, du_last, ncycles, hist, hist_len) &
+      bind(c, name="ndsm_hip_mg_solve") result(ierr)
+    type(c_ptr), value :: handle, hist
+    real(c_double), value :: vc_tol
+    integer(c_int), value :: nmax, hist_len
+    real(c_double), intent(out) :: du_last
+    integer(c_int), intent(out) :: ncycles
+    integer(c_int) :: ierr
+    type(mg_solver), pointer :: s
+    real(c_double), pointer :: hh(:)
+    integer :: nc, ie
+    integer(c_int) :: rc
+    call c_f_pointer(handle, s)
+    if (c_associated(hist) .and. hist_len > 0) then
+      call c_f_pointer(hist, hh, [hist_len])
+      rc = mg_solve(s, vc_tol, int(nmax), du_last, nc, ie, hh)
+    else
+      rc = mg_solve(s, vc_tol, int(nmax), du_last, nc, ie)
+    end if
+    ncycles = nc
+    ierr = merge(rc, int(ie, c_int), rc /= 0)
+  end function
+
+  function ndsm_hip_mg_info(handle, sweeps, unconverged) bind(c, name="ndsm_hip_mg_info") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int64_t), intent(out) :: sweeps, unconverged
+    integer(c_int) :: rc
+    type(mg_solver), pointer :: s
+    call c_f_pointer(handle, s)
+    rc = mg_read_info(s, sweeps, unconverged)
+  end function
+
+end module ndsmh_cabi

@@ -1,0 +1,217 @@
+! libndsm_hip - host-side description of NDSM's grid hierarchy and of the
+! inter-level transfer operators, in the form the HIP kernels consume.
+!
+! What the reference does (and this module must reproduce number for number):
+!   * level count  ngrids = FLOOR(LOG(nmin/2)/LOG(2))      ndsm_vector_potential.f90:60,631-632
+!   * level shapes n_{l+1} = MAX(FLOOR(n_l * 0.5), 1)       ndsm_multigrid_core.f90:215-217
+!   * level meshes: every coarse mesh spans the SAME extent  ndsm_multigrid_core.f90:253-259
+!     q(j) = (j-1) L/(nq-1) + qmin, so h_c/h_f = (n_f-1)/(n_c-1) /= 2 - the grids
+!     are not nested and the transfer weights depend on position.
+!   * prolongation = N-linear interpolation at each fine coordinate
+!     (bracket search ndsm_interp.f90:373-435, weights :138-142)
+!   * restriction = its adjoint times (h_f/h_c)^ndim: for coarse point q0 all
+!     fine points with coordinate in (q0-h_c, q0+h_c]  (ndsm_interp.f90:218-252),
+!     weight prod_d |h_c - |q_f - q0|| h_f / h_c^2       (:229, :276-282)
+!
+! Both operators are tensor products, so instead of a search per point per
+! V-cycle (the reference) the host computes 1-D tables per dimension ONCE per
+! hierarchy - with the same floating-point expressions, hence the same
+! numbers - and the device only gathers and multiplies.
+module ndsmh_grid
+
+  use, intrinsic :: iso_c_binding
+  use ndsmh_iface, only: wp, ik, ndsmk_grid
+  implicit none
+  private
+
+  public :: axis_t, level_t, axis_xfer_t
+  public :: ndsm_level_count, build_levels, build_axis_xfer, fill_grid_desc, locate_uniform
+
+  ! one coordinate axis of one level
+  type :: axis_t
+    real(wp), allocatable :: q(:)
+  end type
+
+  type :: level_t
+    integer(c_int32_t) :: n(3) = 1
+    integer(ik) :: npts = 0
+    type(axis_t) :: ax(3)
+    type(ndsmk_grid) :: g
+  end type
+
+  ! 1-D transfer tables between a fine and a coarse axis (0-based indices, ready
+  ! for the device)
+  type :: axis_xfer_t
+    integer(c_int32_t) :: nf = 1, nc = 1, maxt = 1
+    integer(c_int32_t), allocatable :: plo(:)        ! (nf) lower bracket in the coarse axis
+    real(wp), allocatable :: pwl(:), pwh(:)          ! (nf) weights of upper / lower bracket point
+    integer(c_int32_t), allocatable :: rlo(:), rcnt(:) ! (nc) first fine tap, number of taps
+    real(wp), allocatable :: rw(:, :)                ! (maxt, nc) c2 = |h_c - |q_f - q0||
+    real(wp) :: w2 = 0                               ! h_f / h_c**2
+  end type
+
+contains
+
+  ! Number of grids the reference would use for this (fine) shape.
+  pure function ndsm_level_count(ndim, nshape) result(ng)
+    integer, intent(in) :: ndim
+    integer(c_int32_t), intent(in) :: nshape(:)
+    integer :: ng
+    real(wp), parameter :: base_grid = 2
+    ng = floor(log(real(minval(nshape(1:ndim)), wp) / base_grid) / log(real(2, wp)))
+  end function
+
+  ! Shapes and meshes of all levels; lev(1) is the caller's mesh verbatim.
+  subroutine build_levels(ndim, nshape, qx, qy, qz, ngrids, lev)
+    integer, intent(in) :: ndim, ngrids
+    integer(c_int32_t), intent(in) :: nshape(3)
+    real(wp), intent(in) :: qx(:), qy(:), qz(:)
+    type(level_t), allocatable, intent(out) :: lev(:)
+    integer :: l, d, j, nq
+    real(wp) :: qmin, span
+
+    allocate (lev(ngrids))
+    lev(1)%n = 1
+    lev(1)%n(1:ndim) = nshape(1:ndim)
+    allocate (lev(1)%ax(1)%q(nshape(1)), source=qx(1:nshape(1)))
+    allocate (lev(1)%ax(2)%q(nshape(2)), source=qy(1:nshape(2)))
+    if (ndim == 3) allocate (lev(1)%ax(3)%q(nshape(3)), source=qz(1:nshape(3)))
+
+    do l = 2, ngrids
+      lev(l)%n = 1
+      do d = 1, ndim
+        lev(l)%n(d) = max(floor(lev(l - 1)%n(d) * 0.5_wp), 1)
+      end do
+      do d = 1, ndim
+        nq = lev(l)%n(d)
+        qmin = minval(lev(1)%ax(d)%q)
+        span = maxval(lev(1)%ax(d)%q) - qmin
+        allocate (lev(l)%ax(d)%q(nq))
+        do j = 1, nq
+          lev(l)%ax(d)%q(j) = (j - 1) * span / real(nq - 1, wp) + qmin
+        end do
+      end do
+    end do
+
+    do l = 1, ngrids
+      lev(l)%npts = product(int(lev(l)%n(1:ndim), ik))
+    end do
+  end subroutine
+
+  ! Operator constants and update bounds of one level.
+  ! bcs(1:ndim) = lower faces, bcs(ndim+1:2*ndim) = upper faces, 'D' or 'N'.
+  subroutine fill_grid_desc(ndim, lv, bcs)
+    integer, intent(in) :: ndim
+    type(level_t), intent(inout) :: lv
+    character(len=1), intent(in) :: bcs(:)
+    integer :: d
+    real(wp) :: h, acc
+
+    lv%g%ndim = ndim
+    lv%g%n = lv%n
+    lv%g%lb = 0
+    lv%g%ub = lv%n - 1
+    lv%g%w = 0
+    do d = 1, ndim
+      if (bcs(d) == 'D') lv%g%lb(d) = 1
+      if (bcs(ndim + d) == 'D') lv%g%ub(d) = lv%n(d) - 2
+      h = lv%ax(d)%q(2) - lv%ax(d)%q(1)
+      lv%g%w(d) = 1.0_wp / h**2
+    end do
+    if (ndim == 3) then
+      ! ndsm_optimized.f90:93-94 and :384
+      acc = 2 * (lv%g%w(1) + lv%g%w(2) + lv%g%w(3))
+      lv%g%wc = acc
+      lv%g%w1 = 1.0_wp / acc
+      ! colour of the first half sweep (ndsm_optimized.f90:106): 1-based
+      ! i+j+k == lb(1) (mod 2)  <=>  0-based (i+j+k) mod 2 == [x-lower is 'D']
+      lv%g%first_par = merge(1, 0, bcs(1) == 'D')
+    else
+      ! ndsm_poisson.f90:483-489 accumulates 2*w_d one dimension at a time
+      acc = 0
+      do d = 1, ndim
+        acc = acc + 2.0_wp * lv%g%w(d)
+      end do
+      lv%g%wc = acc
+      lv%g%w1 = 1.0_wp / acc
+      lv%g%first_par = 0      ! red = even i+j (ndsm_poisson.f90:499-501)
+    end if
+    lv%g%all_neumann = merge(1, 0, all(bcs(1:2 * ndim) == 'N'))
+    lv%g%k0 = 0
+    lv%g%nzg = lv%n(3)
+  end subroutine
+
+  ! Bracket of coordinate `c` in the uniform axis q(1:nq): returns the 1-based
+  ! lower index and side = -1 / +1 when c lies at or beyond the first / last
+  ! point, 0 otherwise (same decisions as ndsm_interp.f90:399-433).
+  pure subroutine locate_uniform(q, nq, c, lo, side)
+    real(wp), intent(in) :: q(:)
+    integer, intent(in) :: nq
+    real(wp), intent(in) :: c
+    integer, intent(out) :: lo, side
+    if (c <= q(1)) then
+      lo = 1; side = -1
+    else if (c >= q(nq)) then
+      lo = nq - 1; side = +1
+    else
+      side = 0
+      lo = min(floor((c - q(1)) / (q(2) - q(1))) + 1, nq - 1)
+    end if
+  end subroutine
+
+  subroutine build_axis_xfer(qf, nf, qc, nc, t, ok)
+    real(wp), intent(in) :: qf(:), qc(:)
+    integer, intent(in) :: nf, nc
+    type(axis_xfer_t), intent(out) :: t
+    logical, intent(out) :: ok
+    integer :: i, lo, hi, side, first, last, k
+    real(wp) :: hc, hf, c0, ql, qh, dq, c1
+    integer, allocatable :: f0(:), f1(:)
+
+    ok = .false.
+    if (nf < 2 .or. nc < 2) return
+    t%nf = nf; t%nc = nc
+    allocate (t%plo(nf), t%pwl(nf), t%pwh(nf), t%rlo(nc), t%rcnt(nc))
+
+    ! ---- prolongation: bracket every fine coordinate in the coarse axis
+    do i = 1, nf
+      c0 = qf(i)
+      call locate_uniform(qc, nc, c0, lo, side)
+      ql = qc(lo); qh = qc(lo + 1)
+      dq = qh - ql
+      t%plo(i) = lo - 1
+      t%pwl(i) = +(c0 - ql) / dq
+      t%pwh(i) = -(c0 - qh) / dq
+    end do
+
+    ! ---- restriction: fine taps of every coarse coordinate
+    hc = qc(2) - qc(1)
+    hf = qf(2) - qf(1)
+    t%w2 = hf / hc**2
+    allocate (f0(nc), f1(nc))
+    do i = 1, nc
+      c0 = qc(i)
+      call locate_uniform(qf, nf, c0 - hc, lo, side)
+      first = merge(lo, lo + 1, side < 0)       ! first fine point strictly above c0-hc
+      call locate_uniform(qf, nf, c0 + hc, lo, side)
+      last = merge(lo + 1, lo, side > 0)        ! last fine point at or below c0+hc
+      f0(i) = first; f1(i) = last
+    end do
+    if (any(f1 < f0) .or. any(f0 < 1) .or. any(f1 > nf)) return
+    t%maxt = maxval(f1 - f0 + 1)
+    allocate (t%rw(t%maxt, nc))
+    t%rw = 0
+    do i = 1, nc
+      c0 = qc(i)
+      t%rlo(i) = f0(i) - 1
+      t%rcnt(i) = f1(i) - f0(i) + 1
+      do k = f0(i), f1(i)
+        c1 = abs(qf(k) - c0)
+        t%rw(k - f0(i) + 1, i) = abs(hc - c1)
+      end do
+    end do
+    hi = maxval(t%plo) + 1
+    ok = (minval(t%plo) >= 0) .and. (hi <= nc - 1)
+  end subroutine
+
+end module ndsmh_grid

@@ -1,0 +1,185 @@
+! libndsm_hip - ISO_C_BINDING shim between the Fortran 2003 host driver and the
+! hand-written HIP kernels (ndsm_amd/csrc/ndsm_kernels.h).  Every interface
+! below is a 1:1 image of a C prototype in that header; the two BIND(C) types
+! mirror the C structs member for member.
+!
+! Kinds follow the reference's conventions (ndsm_root.f90:56-61): reals are
+! C doubles, sizes and counters are 64-bit.
+module ndsmh_iface
+
+  use, intrinsic :: iso_c_binding
+  implicit none
+  public
+
+  integer, parameter :: wp = c_double
+  integer, parameter :: ik = c_int64_t
+
+  ! error codes shared with ndsm_kernels.h
+  integer(c_int), parameter :: NDSMK_OK = 0, NDSMK_ENODEV = 9001, NDSMK_EARG = 9002, NDSMK_ENCCL = 9003
+
+  type, bind(c) :: ndsmk_grid
+    integer(c_int32_t) :: ndim = 3
+    integer(c_int32_t) :: n(3) = 1
+    integer(c_int32_t) :: lb(3) = 0, ub(3) = 0
+    integer(c_int32_t) :: first_par = 0
+    integer(c_int32_t) :: all_neumann = 0
+    integer(c_int32_t) :: k0 = 0
+    integer(c_int32_t) :: nzg = 1
+    real(c_double) :: w(3) = 0
+    real(c_double) :: w1 = 0
+    real(c_double) :: wc = 0
+  end type
+
+  type, bind(c) :: ndsmk_xfer
+    integer(c_int32_t) :: nf(3) = 1, nc(3) = 1, maxt(3) = 1
+    type(c_ptr) :: plo(3), pwl(3), pwh(3)
+    type(c_ptr) :: rlo(3), rcnt(3), rw(3)
+    real(c_double) :: w2(3) = 0
+  end type
+
+  interface
+
+    function ndsmk_device_count() bind(c, name="ndsmk_device_count") result(n)
+      import :: c_int
+      integer(c_int) :: n
+    end function
+
+    function ndsmk_init(device) bind(c, name="ndsmk_init") result(rc)
+      import :: c_int
+      integer(c_int), value :: device
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_last_error() bind(c, name="ndsmk_last_error") result(p)
+      import :: c_ptr
+      type(c_ptr) :: p
+    end function
+
+    function ndsmk_alloc(p, bytes) bind(c, name="ndsmk_alloc") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), intent(out) :: p
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_free(p) bind(c, name="ndsmk_free") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_h2d(dst, src, bytes) bind(c, name="ndsmk_h2d") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: dst, src
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_d2h(dst, src, bytes) bind(c, name="ndsmk_d2h") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: dst, src
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_d2d(dst, src, bytes) bind(c, name="ndsmk_d2d") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: dst, src
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_fill0(p, bytes) bind(c, name="ndsmk_fill0") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: p
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_sync() bind(c, name="ndsmk_sync") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_timer_start() bind(c, name="ndsmk_timer_start") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_timer_stop(ms) bind(c, name="ndsmk_timer_stop") result(rc)
+      import :: c_int, c_double
+      real(c_double), intent(out) :: ms
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_relax(g, u, rhs, nsweeps, variant) bind(c, name="ndsmk_relax") result(rc)
+      import :: ndsmk_grid, c_ptr, c_int
+      type(ndsmk_grid), intent(in) :: g
+      type(c_ptr), value :: u, rhs
+      integer(c_int), value :: nsweeps, variant
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_residual(g, u, rhs, r) bind(c, name="ndsmk_residual") result(rc)
+      import :: ndsmk_grid, c_ptr, c_int
+      type(ndsmk_grid), intent(in) :: g
+      type(c_ptr), value :: u, rhs, r
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_restrict(x, r_f, rhs_c, u_c) bind(c, name="ndsmk_restrict") result(rc)
+      import :: ndsmk_xfer, c_ptr, c_int
+      type(ndsmk_xfer), intent(in) :: x
+      type(c_ptr), value :: r_f, rhs_c, u_c
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_prolong_add(x, u_c, u_f) bind(c, name="ndsmk_prolong_add") result(rc)
+      import :: ndsmk_xfer, c_ptr, c_int
+      type(ndsmk_xfer), intent(in) :: x
+      type(c_ptr), value :: u_c, u_f
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_diff_metrics(a, b, n, copy, out2) bind(c, name="ndsmk_diff_metrics") result(rc)
+      import :: c_ptr, c_int64_t, c_int, c_double
+      type(c_ptr), value :: a, b
+      integer(c_int64_t), value :: n
+      integer(c_int), value :: copy
+      real(c_double), intent(out) :: out2(2)
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_solve_exact(g, u, rhs, scratch, ex_tol, use_max, nmax, d_info) &
+        bind(c, name="ndsmk_solve_exact") result(rc)
+      import :: ndsmk_grid, c_ptr, c_int, c_double
+      type(ndsmk_grid), intent(in) :: g
+      type(c_ptr), value :: u, rhs, scratch, d_info
+      real(c_double), value :: ex_tol
+      integer(c_int), value :: use_max, nmax
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_balance_curl(A, B, n3, x, y, z, phi6, span3, dq3, curl_first) &
+        bind(c, name="ndsmk_balance_curl") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: A, B, x, y, z
+      integer(c_int32_t), intent(in) :: n3(3)
+      real(c_double), intent(in) :: phi6(6), span3(3), dq3(3)
+      integer(c_int), value :: curl_first
+      integer(c_int) :: rc
+    end function
+
+  end interface
+
+contains
+
+  ! byte offset into a device allocation
+  function dptr_offset(base, bytes) result(p)
+    type(c_ptr), intent(in) :: base
+    integer(c_size_t), intent(in) :: bytes
+    type(c_ptr) :: p
+    p = transfer(transfer(base, 0_c_intptr_t) + int(bytes, c_intptr_t), p)
+  end function
+
+end module ndsmh_iface

@@ -1,0 +1,406 @@
+! libndsm_hip - device-resident geometric multigrid solver: the V-cycle driver
+! loop in Fortran 2003, every grid operation a HIP kernel.
+!
+! Reference path being replaced (all on the CPU there):
+!   solve_poisson_bvp          ndsm_poisson.f90:63-155      -> mg_solve
+!   v_cycle                    ndsm_multigrid_core.f90:341-377 -> mg_vcycle
+!   fine_to_coarse/coarse_to_fine            :482-560 / :593-684
+!   solve_exact                              :728-800
+!   update_u                                 :1077-1122
+!   new_mg_handle/delete_mg_handle           :165-329      -> mg_create / mg_destroy
+!
+! Differences in mechanism, not in arithmetic:
+!   * all level arrays, the residual scratch and the transfer tables are
+!     allocated once per solver in HBM and stay there; the reference allocates,
+!     zeroes and frees u(l), rhs(l), r_f and cor_f inside every V-cycle
+!     (:528,:542,:557,:647-675).
+!   * a V-cycle enqueues kernels on one HIP stream and never synchronises; the
+!     only host round trip per cycle is the 16-byte convergence metric.
+module ndsmh_mg
+
+  use, intrinsic :: iso_c_binding
+  use ndsmh_iface
+  use ndsmh_grid
+  implicit none
+  private
+
+  public :: mg_solver, mg_create, mg_destroy, mg_vcycle, mg_solve
+  public :: mg_set_u, mg_set_rhs, mg_get_u, mg_zero_rhs, mg_level_ptr, mg_op, mg_read_info
+  public :: mg_set_bcs, mg_export_u, mg_reset_info
+  public :: MG_BUF_U, MG_BUF_RHS, MG_BUF_R
+  public :: MG_OP_RELAX, MG_OP_RESIDUAL, MG_OP_RESTRICT, MG_OP_PROLONG, MG_OP_EXACT, MG_OP_RELAX_COLOR, &
+            MG_OP_RELAX_FUSED
+
+  integer, parameter :: MG_BUF_U = 0, MG_BUF_RHS = 1, MG_BUF_R = 2
+  integer, parameter :: MG_OP_RELAX = 0, MG_OP_RESIDUAL = 1, MG_OP_RESTRICT = 2, MG_OP_PROLONG = 3, &
+                        MG_OP_EXACT = 4, MG_OP_RELAX_COLOR = 5, MG_OP_RELAX_FUSED = 6
+
+  integer(c_size_t), parameter :: R8 = 8_c_size_t, I4 = 4_c_size_t
+
+  type :: dev_level
+    type(c_ptr) :: u = c_null_ptr, rhs = c_null_ptr
+  end type
+
+  type :: dev_xfer
+    type(ndsmk_xfer) :: x
+    type(c_ptr) :: blob = c_null_ptr
+  end type
+
+  type :: mg_solver
+    integer :: ndim = 0, ngrids = 0
+    integer :: ms = 5, nmax_exact = 10000
+    logical :: use_max = .true.
+    real(wp) :: ex_tol = 1.0e-13_wp
+    character(len=1) :: bcs(6) = 'N'
+    type(level_t), allocatable :: lev(:)
+    type(dev_level), allocatable :: dl(:)
+    type(dev_xfer), allocatable :: xf(:)
+    type(c_ptr) :: r = c_null_ptr        ! residual scratch, level-1 sized
+    type(c_ptr) :: prev = c_null_ptr     ! previous iterate of level 1 (update_u)
+    type(c_ptr) :: scr = c_null_ptr      ! coarsest-level scratch
+    type(c_ptr) :: info = c_null_ptr     ! 2 x int64 on the device: exact sweeps, unconverged coarse solves
+    integer(ik) :: vcycles_done = 0
+  end type
+
+contains
+
+  ! ------------------------------------------------------------------
+  ! construction
+  ! ------------------------------------------------------------------
+  function mg_create(s, ndim, nshape, qx, qy, qz, bcs, ngrids_req) result(rc)
+    type(mg_solver), intent(out) :: s
+    integer, intent(in) :: ndim
+    integer(c_int32_t), intent(in) :: nshape(3)
+    real(wp), intent(in) :: qx(:), qy(:), qz(:)
+    character(len=1), intent(in) :: bcs(:)
+    integer, intent(in) :: ngrids_req          ! <= 0: the reference's rule
+    integer(c_int) :: rc
+    integer :: l, d
+    integer(c_size_t) :: nbytes
+
+    rc = NDSMK_EARG
+    if (ndim /= 2 .and. ndim /= 3) return
+    if (any(nshape(1:ndim) < 4)) return        ! the reference needs nmin >= 4 for one grid
+    if (size(bcs) < 2 * ndim) return
+    do d = 1, 2 * ndim
+      if (bcs(d) /= 'D' .and. bcs(d) /= 'N') return
+    end do
+
+    s%ndim = ndim
+    s%bcs = 'N'
+    s%bcs(1:2 * ndim) = bcs(1:2 * ndim)
+    s%ngrids = ndsm_level_count(ndim, nshape)
+    if (ngrids_req > 0) s%ngrids = min(ngrids_req, s%ngrids)
+    if (s%ngrids < 1) return
+
+    rc = ndsmk_init(-1_c_int)
+    if (rc /= 0) return
+
+    call build_levels(ndim, nshape, qx, qy, qz, s%ngrids, s%lev)
+    do l = 1, s%ngrids
+      call fill_grid_desc(ndim, s%lev(l), s%bcs)
+    end do
+
+    allocate (s%dl(s%ngrids))
+    do l = 1, s%ngrids
+      nbytes = int(s%lev(l)%npts, c_size_t) * R8
+      rc = ndsmk_alloc(s%dl(l)%u, nbytes); if (rc /= 0) return
+      rc = ndsmk_alloc(s%dl(l)%rhs, nbytes); if (rc /= 0) return
+      rc = ndsmk_fill0(s%dl(l)%u, nbytes); if (rc /= 0) return
+      rc = ndsmk_fill0(s%dl(l)%rhs, nbytes); if (rc /= 0) return
+    end do
+    nbytes = int(s%lev(1)%npts, c_size_t) * R8
+    rc = ndsmk_alloc(s%r, nbytes); if (rc /= 0) return
+    rc = ndsmk_alloc(s%prev, nbytes); if (rc /= 0) return
+    rc = ndsmk_alloc(s%scr, int(s%lev(s%ngrids)%npts, c_size_t) * R8); if (rc /= 0) return
+    rc = ndsmk_alloc(s%info, 16_c_size_t); if (rc /= 0) return
+    rc = ndsmk_fill0(s%info, 16_c_size_t); if (rc /= 0) return
+
+    allocate (s%xf(max(s%ngrids - 1, 0)))
+    do l = 1, s%ngrids - 1
+      rc = upload_xfer(s, l); if (rc /= 0) return
+    end do
+    rc = 0
+  end function
+
+  ! Build the 1-D tables of the l -> l+1 transfer on the host and pack them
+  ! into one device allocation.
+  function upload_xfer(s, l) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer, intent(in) :: l
+    integer(c_int) :: rc
+    type(axis_xfer_t), target :: t(3)
+    integer :: d
+    logical :: ok
+    integer(c_size_t) :: off, total
+    integer(c_size_t) :: o_plo(3), o_pwl(3), o_pwh(3), o_rlo(3), o_rcnt(3), o_rw(3)
+
+    rc = NDSMK_EARG
+    total = 0
+    do d = 1, s%ndim
+      call build_axis_xfer(s%lev(l)%ax(d)%q, int(s%lev(l)%n(d)), s%lev(l + 1)%ax(d)%q, &
+                           int(s%lev(l + 1)%n(d)), t(d), ok)
+      if (.not. ok) return
+      ! doubles first so that every table stays 8-byte aligned
+      o_pwl(d) = total; total = total + int(t(d)%nf, c_size_t) * R8
+      o_pwh(d) = total; total = total + int(t(d)%nf, c_size_t) * R8
+      o_rw(d) = total; total = total + int(t(d)%maxt, c_size_t) * int(t(d)%nc, c_size_t) * R8
+      o_plo(d) = total; total = total + pad8(int(t(d)%nf, c_size_t) * I4)
+      o_rlo(d) = total; total = total + pad8(int(t(d)%nc, c_size_t) * I4)
+      o_rcnt(d) = total; total = total + pad8(int(t(d)%nc, c_size_t) * I4)
+    end do
+    rc = ndsmk_alloc(s%xf(l)%blob, total); if (rc /= 0) return
+
+    s%xf(l)%x%nf = s%lev(l)%n
+    s%xf(l)%x%nc = s%lev(l + 1)%n
+    s%xf(l)%x%maxt = 1
+    s%xf(l)%x%w2 = 0
+    do d = 1, 3
+      s%xf(l)%x%plo(d) = c_null_ptr; s%xf(l)%x%pwl(d) = c_null_ptr; s%xf(l)%x%pwh(d) = c_null_ptr
+      s%xf(l)%x%rlo(d) = c_null_ptr; s%xf(l)%x%rcnt(d) = c_null_ptr; s%xf(l)%x%rw(d) = c_null_ptr
+    end do
+    do d = 1, s%ndim
+      s%xf(l)%x%maxt(d) = t(d)%maxt
+      s%xf(l)%x%w2(d) = t(d)%w2
+      s%xf(l)%x%pwl(d) = dptr_offset(s%xf(l)%blob, o_pwl(d))
+      s%xf(l)%x%pwh(d) = dptr_offset(s%xf(l)%blob, o_pwh(d))
+      s%xf(l)%x%rw(d) = dptr_offset(s%xf(l)%blob, o_rw(d))
+      s%xf(l)%x%plo(d) = dptr_offset(s%xf(l)%blob, o_plo(d))
+      s%xf(l)%x%rlo(d) = dptr_offset(s%xf(l)%blob, o_rlo(d))
+      s%xf(l)%x%rcnt(d) = dptr_offset(s%xf(l)%blob, o_rcnt(d))
+      rc = ndsmk_h2d(s%xf(l)%x%pwl(d), c_loc(t(d)%pwl), int(t(d)%nf, c_size_t) * R8); if (rc /= 0) return
+      rc = ndsmk_h2d(s%xf(l)%x%pwh(d), c_loc(t(d)%pwh), int(t(d)%nf, c_size_t) * R8); if (rc /= 0) return
+      rc = ndsmk_h2d(s%xf(l)%x%rw(d), c_loc(t(d)%rw), &
+                     int(t(d)%maxt, c_size_t) * int(t(d)%nc, c_size_t) * R8); if (rc /= 0) return
+      rc = ndsmk_h2d(s%xf(l)%x%plo(d), c_loc(t(d)%plo), int(t(d)%nf, c_size_t) * I4); if (rc /= 0) return
+      rc = ndsmk_h2d(s%xf(l)%x%rlo(d), c_loc(t(d)%rlo), int(t(d)%nc, c_size_t) * I4); if (rc /= 0) return
+      rc = ndsmk_h2d(s%xf(l)%x%rcnt(d), c_loc(t(d)%rcnt), int(t(d)%nc, c_size_t) * I4); if (rc /= 0) return
+    end do
+    rc = 0
+  contains
+    pure function pad8(b) result(p)
+      integer(c_size_t), intent(in) :: b
+      integer(c_size_t) :: p
+      p = ((b + 7_c_size_t) / 8_c_size_t) * 8_c_size_t
+    end function
+  end function
+
+  ! Re-target an existing hierarchy at another set of boundary letters: only the
+  ! update bounds / first colour / Neumann flag of the level descriptors change,
+  ! the device arrays and transfer tables are reused.
+  function mg_set_bcs(s, bcs) result(rc)
+    type(mg_solver), intent(inout) :: s
+    character(len=1), intent(in) :: bcs(:)
+    integer(c_int) :: rc
+    integer :: l, d
+    rc = NDSMK_EARG
+    if (size(bcs) < 2 * s%ndim) return
+    do d = 1, 2 * s%ndim
+      if (bcs(d) /= 'D' .and. bcs(d) /= 'N') return
+    end do
+    s%bcs = 'N'
+    s%bcs(1:2 * s%ndim) = bcs(1:2 * s%ndim)
+    do l = 1, s%ngrids
+      call fill_grid_desc(s%ndim, s%lev(l), s%bcs)
+    end do
+    rc = 0
+  end function
+
+  ! device-to-device copy of the level-1 solution into caller-owned HBM
+  function mg_export_u(s, d_dst) result(rc)
+    type(mg_solver), intent(in) :: s
+    type(c_ptr), intent(in) :: d_dst
+    integer(c_int) :: rc
+    rc = ndsmk_d2d(d_dst, s%dl(1)%u, int(s%lev(1)%npts, c_size_t) * R8)
+  end function
+
+  function mg_reset_info(s) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer(c_int) :: rc
+    rc = ndsmk_fill0(s%info, 16_c_size_t)
+  end function
+
+  subroutine mg_destroy(s)
+    type(mg_solver), intent(inout) :: s
+    integer :: l
+    integer(c_int) :: rc
+    if (allocated(s%dl)) then
+      do l = 1, size(s%dl)
+        rc = ndsmk_free(s%dl(l)%u)
+        rc = ndsmk_free(s%dl(l)%rhs)
+      end do
+      deallocate (s%dl)
+    end if
+    if (allocated(s%xf)) then
+      do l = 1, size(s%xf)
+        rc = ndsmk_free(s%xf(l)%blob)
+      end do
+      deallocate (s%xf)
+    end if
+    rc = ndsmk_free(s%r); s%r = c_null_ptr
+    rc = ndsmk_free(s%prev); s%prev = c_null_ptr
+    rc = ndsmk_free(s%scr); s%scr = c_null_ptr
+    rc = ndsmk_free(s%info); s%info = c_null_ptr
+    if (allocated(s%lev)) deallocate (s%lev)
+    s%ngrids = 0
+  end subroutine
+
+  ! ------------------------------------------------------------------
+  ! data movement (host buffers are the caller's; everything blocking)
+  ! ------------------------------------------------------------------
+  function mg_set_u(s, h_u) result(rc)
+    type(mg_solver), intent(inout) :: s
+    type(c_ptr), intent(in) :: h_u
+    integer(c_int) :: rc
+    rc = ndsmk_h2d(s%dl(1)%u, h_u, int(s%lev(1)%npts, c_size_t) * R8)
+  end function
+
+  function mg_set_rhs(s, h_rhs) result(rc)
+    type(mg_solver), intent(inout) :: s
+    type(c_ptr), intent(in) :: h_rhs
+    integer(c_int) :: rc
+    rc = ndsmk_h2d(s%dl(1)%rhs, h_rhs, int(s%lev(1)%npts, c_size_t) * R8)
+  end function
+
+  function mg_zero_rhs(s) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer(c_int) :: rc
+    rc = ndsmk_fill0(s%dl(1)%rhs, int(s%lev(1)%npts, c_size_t) * R8)
+  end function
+
+  function mg_get_u(s, h_u) result(rc)
+    type(mg_solver), intent(inout) :: s
+    type(c_ptr), intent(in) :: h_u
+    integer(c_int) :: rc
+    rc = ndsmk_d2h(h_u, s%dl(1)%u, int(s%lev(1)%npts, c_size_t) * R8)
+  end function
+
+  ! device pointer + element count of a level buffer (tests, bench)
+  function mg_level_ptr(s, level, which, npts) result(p)
+    type(mg_solver), intent(in) :: s
+    integer, intent(in) :: level, which
+    integer(ik), intent(out) :: npts
+    type(c_ptr) :: p
+    p = c_null_ptr; npts = 0
+    if (level < 1 .or. level > s%ngrids) return
+    npts = s%lev(level)%npts
+    select case (which)
+    case (MG_BUF_U); p = s%dl(level)%u
+    case (MG_BUF_RHS); p = s%dl(level)%rhs
+    case (MG_BUF_R)
+      p = s%r
+    end select
+  end function
+
+  function mg_read_info(s, sweeps, unconverged) result(rc)
+    type(mg_solver), intent(in) :: s
+    integer(ik), intent(out) :: sweeps, unconverged
+    integer(c_int) :: rc
+    integer(ik), target :: buf(2)
+    buf = 0
+    rc = ndsmk_d2h(c_loc(buf), s%info, 16_c_size_t)
+    sweeps = buf(1); unconverged = buf(2)
+  end function
+
+  ! ------------------------------------------------------------------
+  ! single grid operations (also the building blocks of the cycle)
+  ! ------------------------------------------------------------------
+  function mg_op(s, op, level, count) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer, intent(in) :: op, level, count
+    integer(c_int) :: rc
+    rc = NDSMK_EARG
+    if (level < 1 .or. level > s%ngrids) return
+    select case (op)
+    case (MG_OP_RELAX)
+      rc = ndsmk_relax(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, int(count, c_int), 0_c_int)
+    case (MG_OP_RELAX_COLOR)
+      rc = ndsmk_relax(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, int(count, c_int), 1_c_int)
+    case (MG_OP_RELAX_FUSED)
+      rc = ndsmk_relax(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, int(count, c_int), 2_c_int)
+    case (MG_OP_RESIDUAL)
+      rc = ndsmk_residual(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, s%r)
+    case (MG_OP_RESTRICT)       ! r(level) -> rhs(level+1), u(level+1) = 0
+      if (level >= s%ngrids) return
+      rc = ndsmk_restrict(s%xf(level)%x, s%r, s%dl(level + 1)%rhs, s%dl(level + 1)%u)
+    case (MG_OP_PROLONG)        ! u(level) += P u(level+1)
+      if (level >= s%ngrids) return
+      rc = ndsmk_prolong_add(s%xf(level)%x, s%dl(level + 1)%u, s%dl(level)%u)
+    case (MG_OP_EXACT)
+      rc = ndsmk_solve_exact(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, s%scr, s%ex_tol, &
+                             merge(1_c_int, 0_c_int, s%use_max), int(s%nmax_exact, c_int), s%info)
+    end select
+  end function
+
+  ! ------------------------------------------------------------------
+  ! one V-cycle from the finest grid; nothing here waits for the GPU
+  ! ------------------------------------------------------------------
+  function mg_vcycle(s) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer(c_int) :: rc
+    integer :: l
+
+    ! descend: pre-smooth, residual, restrict (fine_to_coarse, :482-560)
+    do l = 1, s%ngrids - 1
+      rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
+      rc = mg_op(s, MG_OP_RESIDUAL, l, 1); if (rc /= 0) return
+      rc = mg_op(s, MG_OP_RESTRICT, l, 1); if (rc /= 0) return
+    end do
+
+    ! coarsest grid: iterate the smoother to ex_tol (solve_exact, :728-800)
+    rc = mg_op(s, MG_OP_EXACT, s%ngrids, 1); if (rc /= 0) return
+
+    ! ascend: smooth the coarse problem, interpolate + correct, post-smooth
+    ! (coarse_to_fine, :593-684)
+    do l = s%ngrids, 2, -1
+      rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
+      rc = mg_op(s, MG_OP_PROLONG, l - 1, 1); if (rc /= 0) return
+      rc = mg_op(s, MG_OP_RELAX, l - 1, s%ms); if (rc /= 0) return
+    end do
+    s%vcycles_done = s%vcycles_done + 1
+    rc = 0
+  end function
+
+  ! ------------------------------------------------------------------
+  ! V-cycles to tolerance on the device-resident level-1 problem
+  ! (solve_poisson_bvp, ndsm_poisson.f90:104-150).  ierr = 1 if vc_tol was not
+  ! reached within nmax cycles.  hist (optional) receives du per cycle.
+  ! ------------------------------------------------------------------
+  function mg_solve(s, vc_tol, nmax, du_last, ncycles, ierr, hist) result(rc)
+    type(mg_solver), intent(inout) :: s
+    real(wp), intent(in) :: vc_tol
+    integer, intent(in) :: nmax
+    real(wp), intent(out) :: du_last
+    integer, intent(out) :: ncycles, ierr
+    real(wp), intent(inout), optional :: hist(:)
+    integer(c_int) :: rc
+    real(wp) :: met(2), du
+    integer :: it
+
+    du = huge(du)
+    ncycles = 0
+    ierr = 1
+    ! the caller's array is the "previous iterate" of the first comparison (:122)
+    rc = ndsmk_d2d(s%prev, s%dl(1)%u, int(s%lev(1)%npts, c_size_t) * R8); if (rc /= 0) return
+    do it = 1, nmax
+      rc = mg_vcycle(s); if (rc /= 0) return
+      rc = ndsmk_diff_metrics(s%dl(1)%u, s%prev, s%lev(1)%npts, 1_c_int, met); if (rc /= 0) return
+      if (s%use_max) then
+        du = met(1)
+      else
+        du = met(2) / real(s%lev(1)%npts, wp)
+      end if
+      ncycles = it
+      if (present(hist)) then
+        if (it <= size(hist)) hist(it) = du
+      end if
+      if (du < vc_tol) then         ! strict (:136)
+        ierr = 0
+        exit
+      end if
+    end do
+    du_last = du
+    rc = 0
+  end function
+
+end module ndsmh_mg

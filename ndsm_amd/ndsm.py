@@ -1,0 +1,83 @@
+"""Python front-end with the call contract of the reference's ndsm.py.
+
+`vector_potential` has the reference's signature, defaults and return triple
+(ndsm.py:66-210): it discovers the option slots through the library's getters
+(ndsm.py:155-174), hands Fortran-ordered shape [nx,ny,nz,3] (ndsm.py:161) and
+flat float64 buffers to `ndsm_vector_solve`, and reshapes the results back to
+(3,nz,ny,nx).  The one difference is the default library: ndsm_amd's own
+libndsm_hip.so instead of a sys.path search for "ndsmf.so" - pass `libpath`
+(or `libname` to search) to load anything else that exports the same C ABI,
+e.g. the reference build itself.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+from numpy import ctypeslib as nct
+
+from ._lib import lib_path, NdsmHipError
+
+
+def get_lib_path(libname):
+    """All files called `libname` below the entries of sys.path (ndsm.py:42-62)."""
+    hits = set()
+    for base in sys.path:
+        for root, _dirs, files in os.walk(base):
+            if libname in files:
+                hits.add(os.path.join(root, libname))
+    return list(hits)
+
+
+def vector_potential(x, y, z, b, niterex_max=10000, ncycles_max=1024, ex_tol=1e-13, vc_tol=1e-10, ms=5, mean=False,
+                     libname=None, libpath=None, debug=False):
+    """Vector potential A and B = curl A of the current-free field whose normal
+    component on the six box faces is taken from `b` (3,nz,ny,nx).
+
+    Returns (ierr, A, B) with A, B shaped (3,nz,ny,nx); ierr != 0 flags a V-cycle
+    iteration that did not reach vc_tol (codes >= 9001: device/runtime error).
+    """
+    if libpath is None:
+        if libname is None:
+            libpath = lib_path()
+        else:
+            found = get_lib_path(libname)
+            if len(found) == 0:
+                raise ValueError("Could not locate {:s}".format(libname))
+            if len(found) > 1:
+                raise ValueError("More than once instance of {:s} found\n {:s}".format(libname, str(found)))
+            libpath = found[0]
+    if not os.path.exists(libpath):
+        raise NdsmHipError(f"{libpath} not found - build it with `make -C ndsm_amd`; there is no CPU fallback")
+    try:
+        lib = ctypes.cdll.LoadLibrary(libpath)
+    except OSError as exc:
+        raise ValueError("Could not load library at " + libpath) from exc
+
+    vec_i = nct.ndpointer(np.intc, ndim=1, flags=("C", "A", "W"))
+    vec_d = nct.ndpointer(np.float64, ndim=1, flags=("C", "A", "W"))
+    lib.ndsm_vector_solve.argtypes = [ctypes.c_size_t, vec_i, vec_i, vec_d, vec_d, vec_d, vec_d, vec_d, vec_d]
+    lib.ndsm_vector_solve.restype = ctypes.c_int
+
+    nopt = lib.get_iopt_len()
+    nshape = np.array(b.shape[::-1], dtype=np.intc)
+    ioptc = np.zeros(nopt, dtype=np.intc)
+    ropt = np.zeros(nopt, dtype=np.float64)
+
+    slots = {"ms": lib.get_iopt_ms(), "ncycles": lib.get_iopt_ncycles(), "nmaxex": lib.get_iopt_iopt_nmaxex(),
+             "debug": lib.get_iopt_debug(), "dumax": lib.get_iopt_dumax(), "vtol": lib.get_ropt_vtol(),
+             "ctol": lib.get_ropt_ctol()}
+    if any(v < 0 or v >= nopt for v in slots.values()):
+        raise Exception("Option vector (IOPT) index out of bounds. This shouldn't occur.")
+    ioptc[slots["ms"]] = ms
+    ioptc[slots["ncycles"]] = ncycles_max
+    ioptc[slots["nmaxex"]] = niterex_max
+    ropt[slots["vtol"]] = vc_tol
+    ropt[slots["ctol"]] = ex_tol
+    ioptc[slots["debug"]] = lib.get_iopt_true() if debug else lib.get_iopt_false()
+    ioptc[slots["dumax"]] = lib.get_iopt_false() if mean else lib.get_iopt_true()
+
+    apot = np.zeros(b.size, dtype=np.float64)
+    bflat = b.flatten()
+    ierr = lib.ndsm_vector_solve(ctypes.c_size_t(b.size), nshape, ioptc, ropt, x, y, z, apot, bflat)
+    return ierr, apot.reshape(nshape[::-1]), bflat.reshape(nshape[::-1])

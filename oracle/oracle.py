@@ -23,6 +23,30 @@ PORT_LIB = os.path.join(HERE, "liboracle.so")
 REFK_LIB = os.path.join(HERE, "_ref", "libndsm_refk.so")
 REF_LIB = os.path.join(HERE, "_ref", "ndsmf.so")
 
+
+
+def usable_cpus(cap=16):
+    """CPUs this process may really use: affinity mask, cgroup quota, and `cap`.
+    A GPU box shows 256 logical CPUs under a 16-CPU quota; an OpenMP team of 256
+    spinning threads there does not finish (libgomp spin-wait), so the checkers
+    never run wider than this."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def _omp_env():
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("OMP_DYNAMIC", "FALSE")
+    return int(os.environ["OMP_NUM_THREADS"])
+
+
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip64 = ctypes.POINTER(ctypes.c_int64)
 
@@ -59,6 +83,7 @@ def uniform_mesh(nshape, h=None):
 class Oracle:
     def __init__(self, kind="port"):
         self.kind = kind
+        self.threads = _omp_env()      # before the OpenMP runtime is loaded
         if kind == "port":
             self.lib = ctypes.CDLL(PORT_LIB)
             self.p = "orc_"
