@@ -84,9 +84,14 @@ int ndsmk_timer_stop(double *ms);           /* blocking; elapsed between start a
 /* ---- kernels ------------------------------------------------------- */
 /* nsweeps full red-black Gauss-Seidel sweeps (ndsm_optimized.f90:40-191 in
  * 3-D, ndsm_poisson.f90:451-549 in 2-D incl. the all-Neumann mean shift).
- * variant: 0 = pick the fastest valid kernel, 1 = two-pass colour kernels,
- * 2 = fused z-streaming kernel (3-D only). */
-int ndsmk_relax(const ndsmk_grid *g, double *u, const double *rhs, int nsweeps, int variant);
+ * variant: 0 = pick the fastest valid kernel, 1 = two-pass colour kernels (in
+ * place), 2 = fused z-streaming kernel (3-D only, out of place).
+ * ualt: a second array of the level's size (may be NULL: colour kernels only).
+ * The fused kernel ping-pongs u <-> ualt once per sweep; on return
+ * *result_in_alt = 1 means the swept field is in ualt and the caller must swap
+ * its two pointers (result_in_alt == NULL: it is copied back into u). */
+int ndsmk_relax(const ndsmk_grid *g, double *u, double *ualt, const double *rhs, int nsweeps, int variant,
+                int *result_in_alt);
 /* r = rhs - L u, zero on Dirichlet faces (ndsm_optimized.f90:346-447 / ndsm_poisson.f90:280-353) */
 int ndsmk_residual(const ndsmk_grid *g, const double *u, const double *rhs, double *r);
 /* rhs_c = R r_f ; also u_c = 0 if u_c != NULL (ndsm_multigrid_core.f90:551,557-558) */

@@ -208,7 +208,7 @@ extern "C" int ndsmk_solve_exact(const ndsmk_grid *gp, double *u, const double *
       converged = 1;
       break;
     }
-    if (int rc = ndsmk_relax(gp, u, rhs, 1, 0)) return rc;
+    if (int rc = ndsmk_relax(gp, u, nullptr, rhs, 1, 1, nullptr)) return rc;
     if (int rc = ndsmk_diff_metrics(u, scratch, n, 1, m)) return rc;  // metrics, then u_sav <- u
     du = use_max ? m[0] : m[1] / (double)n;
     ++sweeps;

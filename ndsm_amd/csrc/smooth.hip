@@ -14,7 +14,7 @@
 #include "common.hpp"
 
 namespace ndsm {
-int launch_rbgs3_fused(const ndsmk_grid &g, double *u, const double *rhs, bool *handled);
+int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, bool *handled);
 int launch_mean_shift(double *u, int64_t n);
 }
 
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void rbgs2_color(double *__restrict__ u, const
 
 }  // namespace
 
-extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, const double *rhs, int nsweeps, int variant) {
+extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, double *ualt, const double *rhs, int nsweeps,
+                           int variant, int *result_in_alt) {
   NDSM_REQUIRE_READY();
   const ndsmk_grid g = *gp;
   NDSM_CHECK_ARG(g.ndim == 2 || g.ndim == 3);
@@ -87,12 +88,19 @@ extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, const double *rhs, i
   hipStream_t s = ndsm::stream();
   const int mx = g.ub[0] - g.lb[0] + 1, my = g.ub[1] - g.lb[1] + 1, mz = g.ub[2] - g.lb[2] + 1;
   if (mx <= 0 || my <= 0 || (g.ndim == 3 && mz <= 0)) return 0;  // nothing to update
+  double *const u_entry = u;
+  if (result_in_alt) *result_in_alt = 0;
   for (int sw = 0; sw < nsweeps; ++sw) {
     if (g.ndim == 3) {
       bool done = false;
       if (variant != 1) {
-        int rc = ndsm::launch_rbgs3_fused(g, u, rhs, &done);
+        int rc = ndsm::launch_rbgs3_fused(g, u, ualt, rhs, &done);
         if (rc) return rc;
+        if (done) {  // the sweep landed in the other array
+          double *t = u;
+          u = ualt;
+          ualt = t;
+        }
         if (!done && variant == 2)
           return ndsm::fail(NDSMK_EARG, "fused smoother does not support this level shape", __FILE__, __LINE__);
       }
@@ -117,6 +125,13 @@ extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, const double *rhs, i
     if (g.all_neumann) {
       int rc = ndsm::launch_mean_shift(u, npts);
       if (rc) return rc;
+    }
+  }
+  if (u != u_entry) {
+    if (result_in_alt) {
+      *result_in_alt = 1;
+    } else {  // caller cannot swap: bring the result home
+      NDSM_HIP(hipMemcpyAsync(u_entry, u, sizeof(double) * (size_t)npts, hipMemcpyDeviceToDevice, s));
     }
   }
   return 0;

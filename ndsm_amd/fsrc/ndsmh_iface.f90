@@ -112,11 +112,12 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
-    function ndsmk_relax(g, u, rhs, nsweeps, variant) bind(c, name="ndsmk_relax") result(rc)
+    function ndsmk_relax(g, u, ualt, rhs, nsweeps, variant, result_in_alt) bind(c, name="ndsmk_relax") result(rc)
       import :: ndsmk_grid, c_ptr, c_int
       type(ndsmk_grid), intent(in) :: g
-      type(c_ptr), value :: u, rhs
+      type(c_ptr), value :: u, ualt, rhs
       integer(c_int), value :: nsweeps, variant
+      integer(c_int), intent(out) :: result_in_alt
       integer(c_int) :: rc
     end function
 

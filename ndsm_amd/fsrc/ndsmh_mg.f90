@@ -39,6 +39,7 @@ module ndsmh_mg
 
   type :: dev_level
     type(c_ptr) :: u = c_null_ptr, rhs = c_null_ptr
+    type(c_ptr) :: ualt = c_null_ptr   ! ping-pong partner of u for the out-of-place fused smoother
   end type
 
   type :: dev_xfer
@@ -106,6 +107,7 @@ contains
       nbytes = int(s%lev(l)%npts, c_size_t) * R8
       rc = ndsmk_alloc(s%dl(l)%u, nbytes); if (rc /= 0) return
       rc = ndsmk_alloc(s%dl(l)%rhs, nbytes); if (rc /= 0) return
+      rc = ndsmk_alloc(s%dl(l)%ualt, nbytes); if (rc /= 0) return
       rc = ndsmk_fill0(s%dl(l)%u, nbytes); if (rc /= 0) return
       rc = ndsmk_fill0(s%dl(l)%rhs, nbytes); if (rc /= 0) return
     end do
@@ -227,6 +229,7 @@ contains
     if (allocated(s%dl)) then
       do l = 1, size(s%dl)
         rc = ndsmk_free(s%dl(l)%u)
+        rc = ndsmk_free(s%dl(l)%ualt)
         rc = ndsmk_free(s%dl(l)%rhs)
       end do
       deallocate (s%dl)
@@ -309,15 +312,21 @@ contains
     type(mg_solver), intent(inout) :: s
     integer, intent(in) :: op, level, count
     integer(c_int) :: rc
+    integer(c_int) :: swapped
+    integer :: variant
+    type(c_ptr) :: tmp
     rc = NDSMK_EARG
     if (level < 1 .or. level > s%ngrids) return
     select case (op)
-    case (MG_OP_RELAX)
-      rc = ndsmk_relax(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, int(count, c_int), 0_c_int)
-    case (MG_OP_RELAX_COLOR)
-      rc = ndsmk_relax(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, int(count, c_int), 1_c_int)
-    case (MG_OP_RELAX_FUSED)
-      rc = ndsmk_relax(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, int(count, c_int), 2_c_int)
+    case (MG_OP_RELAX, MG_OP_RELAX_COLOR, MG_OP_RELAX_FUSED)
+      variant = merge(0, merge(1, 2, op == MG_OP_RELAX_COLOR), op == MG_OP_RELAX)
+      rc = ndsmk_relax(s%lev(level)%g, s%dl(level)%u, s%dl(level)%ualt, s%dl(level)%rhs, int(count, c_int), &
+                       int(variant, c_int), swapped)
+      if (rc == 0 .and. swapped /= 0) then      ! the swept field lives in the partner array now
+        tmp = s%dl(level)%u
+        s%dl(level)%u = s%dl(level)%ualt
+        s%dl(level)%ualt = tmp
+      end if
     case (MG_OP_RESIDUAL)
       rc = ndsmk_residual(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, s%r)
     case (MG_OP_RESTRICT)       ! r(level) -> rhs(level+1), u(level+1) = 0
