@@ -1,0 +1,124 @@
+/* libndsm_hip - C ABI of the MI355X-native multigrid path for NDSM.
+ *
+ * PART 1 is the drop-in boundary: exactly the dynamic symbols the reference's
+ * shared object ndsmf.so exports (verified with `nm -D` on a build of
+ * /root/reference/fortran), i.e. what its Python front-end binds through
+ * ctypes (ndsm.py:136-207).  Names, argument lists, option-slot values and
+ * return conventions are the reference's; each prototype cites the
+ * BIND(C) procedure it replaces.
+ *
+ * PART 2 is additive (SURVEY.md 8b last row, 8f-4): a scalar Poisson entry, a
+ * persistent device-resident solver handle, timing hooks.  Nothing in part 1
+ * changes meaning because part 2 exists; all additive option slots are slots
+ * the reference leaves unused (value 0 = reference behaviour).
+ *
+ * All arrays are Fortran order (x fastest): a numpy array of shape (3,nz,ny,nx)
+ * in C order IS the (nx,ny,nz,3) array meant here (ndsm.py:161,210).
+ * Everything is double precision; sizes in the reference ABI are C int / size_t.
+ *
+ * Errors: 0 = ok, 1 = V-cycle iteration did not reach vc_tol (reference
+ * semantics), >= 9001 = device/runtime failure (text via ndsm_hip_last_error
+ * and on stderr).  The library has no CPU fallback: without an MI355X every
+ * solve returns 9001.  It never calls exit()/STOP (the reference does on
+ * internal asserts, ndsm_root.f90:317-455).
+ *
+ * Threading: blocking calls, one library-owned HIP stream; not re-entrant (as
+ * the reference: module-global DEBUG flag, ndsm_root.f90:64).
+ */
+#ifndef NDSM_HIP_H
+#define NDSM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* =====================================================================
+ * PART 1 - the reference ABI
+ * ===================================================================== */
+
+/* Replaces ndsm_vector_solve, fortran/ndsm_python_wrapper.f90:56-158.
+ *   nsize    nx*ny*nz*3                                   (by value, :64)
+ *   nshape4  [nx, ny, nz, 3]                              (:65, ndsm.py:161)
+ *   ioptc    16 integer options, in/out; slots from the getters below
+ *   ropt     16 real options, in/out
+ *   x,y,z    mesh vectors of length nx, ny, nz (uniform spacing assumed)
+ *   A        in: initial guess of the three Laplace solves (ndsm.py passes
+ *            zeros); out: vector potential, (nx,ny,nz,3)
+ *   B        in: field whose NORMAL component on the six faces is the
+ *            boundary data; out: curl A, (nx,ny,nz,3)
+ * returns ioptc[IOPT_IERR]: 0 ok, 1 not converged / bad mesh (see DESIGN.md
+ * quirk Q3' for which solve's flag the reference actually returns). */
+int ndsm_vector_solve(size_t nsize, const int *nshape4, int *ioptc, double *ropt, const double *x,
+                      const double *y, const double *z, double *A, double *B);
+
+/* Option-slot getters, fortran/ndsm_python_wrapper.f90:164-234.  ndsm.py never
+ * hard-codes a slot; it asks the library (ndsm.py:155-174). */
+int get_iopt_len(void);         /* :164  -> 16 */
+int get_iopt_ierr(void);        /* :170  -> 16 (sic: the reference returns IOPT_LEN, not IOPT_IERR = 3) */
+int get_iopt_ms(void);          /* :176  -> 0  smoothing sweeps */
+int get_iopt_ncycles(void);     /* :182  -> 1  max V-cycles */
+int get_iopt_debug(void);       /* :188  -> 5 */
+int get_iopt_dumax(void);       /* :194  -> 6  1: max|du| metric, 0: mean|du| */
+int get_iopt_iopt_nmaxex(void); /* :200  -> 7  max sweeps of the coarsest-grid solve (the doubled "iopt" is the reference's name) */
+int get_iopt_true(void);        /* :206  -> 1 */
+int get_iopt_false(void);       /* :212  -> 0 */
+int get_ropt_tim(void);         /* :218  -> 2  out: wall time of the call, seconds */
+int get_ropt_vtol(void);        /* :224  -> 0  V-cycle tolerance */
+int get_ropt_ctol(void);        /* :230  -> 1  coarsest-grid tolerance */
+
+/* =====================================================================
+ * PART 2 - additive exports
+ * ===================================================================== */
+
+/* additive option slots (unused in the reference, ndsm_vector_potential.f90:40-57) */
+int get_iopt_fail3d(void);   /* -> 8  out: bit c set if 3-D solve c (0=Ax,1=Ay,2=Az) missed vc_tol */
+int get_iopt_ngrids(void);   /* -> 9  in : cap on the number of grid levels, 0 = reference rule
+                                          floor(log2(nmin/2)) (ndsm_vector_potential.f90:631-632) */
+int get_iopt_ncyc_out(void); /* -> 10 out: V-cycles used by the last solve that iterated */
+int get_ropt_dulast(void);   /* -> 3  out: du of its last V-cycle */
+
+int ndsm_hip_device_count(void);
+int ndsm_hip_init(int device);               /* < 0: LOCAL_RANK % device count; idempotent */
+void ndsm_hip_last_error(char *buf, int len);
+int ndsm_hip_sync(void);                     /* wait for the library stream */
+int ndsm_hip_timer_start(void);              /* hipEventRecord on the library stream */
+int ndsm_hip_timer_stop(double *ms);         /* record + synchronise + elapsed */
+
+/* laplace(u) = rhs with 'D'/'N' faces; the scalar problem the reference only
+ * reaches internally (solve_poisson_bvp, ndsm_poisson.f90:63-155).
+ *   bcs     2*ndim letters: lower faces of dim 1..ndim, then upper faces
+ *           (RESHAPE(copt,[ndim,2]), ndsm_poisson.f90:244-245)
+ *   u       in: initial guess INCLUDING the Dirichlet face values; out: solution
+ *   rhs     may be NULL (= 0);   hist may be NULL (else du per V-cycle)
+ * options in the same slots as ndsm_vector_solve; returns 0 / 1 / >= 9001. */
+int ndsm_hip_poisson_solve(int ndim, const int *nshape, const double *x, const double *y,
+                           const double *z, const char *bcs, int *ioptc, double *ropt, double *u,
+                           const double *rhs, double *hist, int hist_len);
+
+/* ---- persistent solver: hierarchy, tables and level arrays stay in HBM ---- */
+int ndsm_hip_mg_create(int ndim, const int *nshape, const double *x, const double *y,
+                       const double *z, const char *bcs, int ngrids /* 0 = reference rule */, int ms,
+                       double ex_tol, int du_max, int nmax_exact, void **handle);
+int ndsm_hip_mg_destroy(void *handle);
+int ndsm_hip_mg_levels(void *handle, int ngrids_cap, int *shapes /* [ngrids_cap][3] */); /* returns ngrids */
+int ndsm_hip_mg_set_ms(void *handle, int ms);
+/* which: 0 = u, 1 = rhs, 2 = residual scratch (level-1 sized) */
+int ndsm_hip_mg_upload(void *handle, int level, int which, const double *host);
+int ndsm_hip_mg_download(void *handle, int level, int which, double *host);
+/* op: 0 relax (count sweeps), 1 residual -> scratch, 2 restrict scratch(level) -> rhs(level+1)
+ * and zero u(level+1), 3 u(level) += P u(level+1), 4 coarsest-grid solve, 5/6 relax forced to
+ * the two-pass / fused kernel.  Asynchronous. */
+int ndsm_hip_mg_op(void *handle, int op, int level, int count);
+int ndsm_hip_mg_vcycle(void *handle, int ncycles);   /* asynchronous, no convergence test */
+/* V-cycles to vc_tol: returns 0 converged, 1 not, >= 9001 error */
+int ndsm_hip_mg_solve(void *handle, double vc_tol, int nmax, double *du_last, int *ncycles,
+                      double *hist, int hist_len);
+int ndsm_hip_mg_info(void *handle, int64_t *exact_sweeps, int64_t *unconverged_coarse_solves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
