@@ -87,12 +87,35 @@ def cpu_baseline(seconds_budget=20.0):
             "ms_per_sweep": per_sweep * 1e3}
 
 
+def slab_window_problem(n3, sl):
+    """window [k0, k0+nloc) ∩ [0, nz) of the Ax boundary problem on an (nx, ny, nz) box (equal spacing)"""
+    nx, ny, nz = n3
+    x = np.linspace(0.0, 1.0, nx)
+    dx = x[1] - x[0]
+    y = np.arange(ny) * dx
+    z = np.arange(nz) * dx
+    a, b = max(sl["k0"], 0), min(sl["k0"] + sl["nloc"], nz)
+    wn = np.pi
+    l = np.sqrt(2 * wn ** 2)
+    ax = lambda X, Y, Z: -np.cos(wn * X) * np.sin(wn * Y) * np.exp(-l * Z)  # noqa: E731
+    u = np.zeros((b - a, ny, nx))
+    Zg, Xg = np.meshgrid(z[a:b], x, indexing="ij")
+    u[:, 0, :] = ax(Xg, y[0], Zg)
+    u[:, -1, :] = ax(Xg, y[-1], Zg)
+    Yg, Xg = np.meshgrid(y, x, indexing="ij")
+    if a == 0:
+        u[0] = ax(Xg, Yg, z[0])
+    if b == nz:
+        u[-1] = ax(Xg, Yg, z[-1])
+    return [x, y, z], u, a
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=512, help="points per dimension of the fine grid")
+    ap.add_argument("--n", type=int, default=512, help="points per dimension of the fine grid (1 GPU)")
     ap.add_argument("--ms", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -100,15 +123,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # libndsm_hip FIRST: it loads /opt/rocm's libamdhip64.so.7 / librccl.so.1.  PyTorch bundles a
+    # second ROCm stack under the same SONAMEs; whichever is loaded first serves the whole process,
+    # so torch is imported afterwards and used for its CPU (gloo) rendezvous only - the device is
+    # synchronised through the library's own stream (ndsm_hip_sync), not torch.cuda.synchronize().
     import ndsm_amd
     from ndsm_amd import _lib
     L = ndsm_amd.load_library()
@@ -116,24 +137,63 @@ def main():
     if rc != 0:
         raise SystemExit("libndsm_hip: " + _lib.last_error(L))
 
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(_lib.dist_unique_id(L)), dtype=torch.uint8).clone()
+        dist.broadcast(uid, 0)
+        _lib.dist_init(rank, world, uid.numpy().tobytes(), L)     # RCCL communicator over xGMI
+
     def barrier_sync():
         _lib._check(L.ndsm_hip_sync(), "sync", L)
         if dist is not None:
             dist.barrier()
 
-    n, ms = args.n, args.ms
-    mesh, u0 = boundary_problem(n)
-    S = _lib.MGSolver([n, n, n], mesh, "NDDNDD", ms=ms)
-    S.upload(1, _lib.BUF_U, u0)
-    S.upload(1, _lib.BUF_RHS, np.zeros_like(u0))
-    del u0
-    npts = float(n) ** 3
+    ms = args.ms
+    if world == 1:
+        n = args.n
+        n3 = [n, n, n]
+        mesh, u0 = boundary_problem(n)
+        S = _lib.MGSolver(n3, mesh, "NDDNDD", ms=ms)
+        S.upload(1, _lib.BUF_U, u0)
+        S.upload(1, _lib.BUF_RHS, np.zeros_like(u0))
+        del u0
+        run_cycles = S.vcycle
+        ngrids = S.ngrids
+        workload = (f"{n}^3 vector-potential Ax component, one V-cycle per step (ms={ms}, {ngrids} grids), "
+                    "config[2] of BASELINE.json")
+        parallelism = "single GPU"
+        scaling = "weak"
+    else:
+        # BASELINE config[3]: 1024 x 1024 x 512 Poisson, level 1 z-slab decomposed over the ranks,
+        # RCCL halo exchange between sweeps, levels >= 2 on rank 0
+        n3 = [1024, 1024, 512]
+        x = np.linspace(0.0, 1.0, n3[0])
+        dx = x[1] - x[0]
+        mesh = [x, np.arange(n3[1]) * dx, np.arange(n3[2]) * dx]
+        S = _lib.World(n3, mesh, "NDDNDD", world, rank, ms=ms, lib=L)
+        _m, win, a = slab_window_problem(n3, S.slabs[0])
+        S.upload_window(1, _lib.BUF_U, win, a)                    # rhs stays zero (Laplace)
+        del win
+        run_cycles = S.vcycle
+        ngrids = 8
+        workload = (f"1024x1024x512 Poisson (Ax boundary data), one V-cycle per step (ms={ms}), "
+                    "config[3] of BASELINE.json")
+        parallelism = f"level 1 in {world} z-slabs (RCCL send/recv halo, 2 planes per neighbour per sweep), levels>=2 on rank 0"
+        scaling = "strong"
+    npts = float(n3[0]) * n3[1] * n3[2]
 
     # ---- the timed region: K V-cycles ------------------------------------
-    S.vcycle(args.warmup)
+    run_cycles(args.warmup)
     barrier_sync()
     t0 = time.perf_counter()
-    S.vcycle(args.steps)
+    run_cycles(args.steps)
     barrier_sync()
     el = time.perf_counter() - t0
     if dist is not None:
@@ -145,52 +205,67 @@ def main():
 
     # ---- dominant kernel: level-1 smoother sweeps under HIP events ---------
     nsw = 20
-    S.op(_lib.OP_RELAX, 1, 2)
-    S.sync()
-    sm_ms = S.timed(lambda: S.op(_lib.OP_RELAX, 1, nsw)) / nsw
-    achieved = BYTES_PER_LUP * npts / (sm_ms * 1e-3) / 1e9
-    # residual + V-cycle breakdown helpers
-    rs_ms = S.timed(lambda: [S.op(_lib.OP_RESIDUAL, 1) for _ in range(5)]) / 5
-    sweeps, unconv = S.info()
+    if world == 1:
+        S.op(_lib.OP_RELAX, 1, 2)
+        S.sync()
+        sm_ms = S.timed(lambda: S.op(_lib.OP_RELAX, 1, nsw)) / nsw
+        rs_ms = S.timed(lambda: [S.op(_lib.OP_RESIDUAL, 1) for _ in range(5)]) / 5
+        sweeps, unconv = S.info()
+        sweeps_per_cycle = sweeps / max(1, args.steps + args.warmup)
+    else:
+        S.relax(2)
+        barrier_sync()
+        sm_ms = S.timed(lambda: S.relax(nsw)) / nsw               # includes the halo exchanges
+        if dist is not None:
+            import torch
+            t = torch.tensor([sm_ms], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sm_ms = float(t[0])
+        rs_ms = None
+        sweeps_per_cycle = None
+    achieved = BYTES_PER_LUP * npts / (sm_ms * 1e-3) / 1e9         # whole job
     S.close()
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1:
         try:
             traffic = json.load(open(tpath)).get("smoother_sweep_bytes_per_launch")
         except Exception:
             traffic = None
 
     if rank != 0:
+        if dist is not None:
+            dist.barrier()
         return
     out = {
-        "metric": "fine-grid LUP/s (RB-GS smoother updates per second of V-cycle time, 512^3 fp64)",
-        "value": 2 * ms * npts * world / (ms_per_step * 1e-3),
+        "metric": "fine-grid LUP/s (RB-GS smoother updates per second of V-cycle time, fp64)",
+        "value": 2 * ms * npts / (ms_per_step * 1e-3),
         "unit": "LUP/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{n}^3 vector-potential Ax component, one V-cycle per step (ms={ms}, "
-                               f"{S.ngrids} grids), config[2] of BASELINE.json",
-                   "global_points": int(npts) * world,
-                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
-        "vcycles_per_s": world / (ms_per_step * 1e-3),
+        "config": {"workload": workload, "global_points": int(npts), "parallelism": parallelism},
+        "vcycles_per_s": 1.0 / (ms_per_step * 1e-3),
         "smoother": {"ms_per_sweep": sm_ms, "LUPs_per_s": npts / (sm_ms * 1e-3), "residual_ms": rs_ms},
-        "coarse_exact_sweeps_per_cycle": sweeps / max(1, args.steps + args.warmup),
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "level-1 RB-GS sweep (red+black)", "bytes_per_lup": BYTES_PER_LUP},
+        "coarse_exact_sweeps_per_cycle": sweeps_per_cycle,
+        "roofline": {"bound": "hbm", "achieved": achieved / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / world / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "level-1 RB-GS sweep (red+black, fused)" + ("" if world == 1 else ", per GPU, halo exchange included"),
+                     "bytes_per_lup": BYTES_PER_LUP},
+        "rocm_stack": _lib.bound_libs(L),
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
 
 
 if __name__ == "__main__":

@@ -33,7 +33,11 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise NdsmHipError(f"{p} not found - build it with `make -C ndsm_amd` "
                            "(or __graft_entry__.build()); there is no CPU fallback")
-    L = ctypes.CDLL(p)
+    # RTLD_DEEPBIND: the library and its own dependencies (/opt/rocm's libamdhip64, librccl) are
+    # searched BEFORE the global scope.  Without it, a process that imported PyTorch first would
+    # bind our hip*/nccl* calls to the second ROCm stack torch bundles (torch loads it RTLD_GLOBAL).
+    mode = os.RTLD_NOW | os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0)
+    L = ctypes.CDLL(p, mode=mode)
     L.ndsm_vector_solve.restype = ctypes.c_int
     L.ndsm_hip_last_error.argtypes = [ctypes.c_char_p, ctypes.c_int]
     L.ndsm_hip_last_error.restype = None
@@ -51,9 +55,31 @@ def load_library(path=None):
     L.ndsm_hip_mg_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     L.ndsm_hip_poisson_solve.argtypes = [ctypes.c_int, _ip, _dp, _dp, _dp, ctypes.c_char_p, _ip, _dp, _dp, _dp, _dp,
                                          ctypes.c_int]
+    L.ndsm_hip_dist_unique_id.argtypes = [ctypes.c_char_p]
+    L.ndsm_hip_dist_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    L.ndsm_hip_slab_plan.argtypes = [_ip, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _ip]
+    L.ndsm_hip_world_create.argtypes = [_ip, _dp, _dp, _dp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_void_p)]
+    L.ndsm_hip_world_destroy.argtypes = [ctypes.c_void_p]
+    L.ndsm_hip_world_nlocal.argtypes = [ctypes.c_void_p]
+    L.ndsm_hip_world_slab.argtypes = [ctypes.c_void_p, ctypes.c_int, _ip]
+    L.ndsm_hip_world_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int]
+    L.ndsm_hip_world_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
+    L.ndsm_hip_world_relax.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.ndsm_hip_world_vcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.ndsm_hip_world_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, _dp, _ip, _dp, ctypes.c_int]
     if path is None:
         _LIB = L
     return L
+
+
+def bound_libs(L=None):
+    """paths of the HIP and RCCL shared objects our calls are bound to"""
+    L = L or load_library()
+    buf = ctypes.create_string_buffer(1024)
+    L.ndsmk_bound_libs(buf, 1024)
+    return dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
 
 
 def last_error(L=None):
@@ -163,6 +189,117 @@ class MGSolver:
         ms = ctypes.c_double(0)
         _check(self.L.ndsm_hip_timer_stop(ctypes.byref(ms)), "timer_stop", self.L)
         return ms.value
+
+
+SLAB_FIELDS = ("rank", "z0", "z1", "g", "nloc", "k0", "ck0", "ck1", "pk0", "pk1", "cb0", "cb1")
+
+
+def slab_plan(nshape, mesh, nranks, ngrids=0, lib=None):
+    """The z-slab plan every rank derives (host arithmetic only - works without a GPU)."""
+    L = lib or load_library()
+    ns = np.asarray(nshape, dtype=np.intc)
+    m = [_f64(v) for v in mesh]
+    out = np.zeros((nranks, 12), dtype=np.intc)
+    rc = L.ndsm_hip_slab_plan(ns.ctypes.data_as(_ip), _d(m[0]), _d(m[1]), _d(m[2]), int(ngrids), int(nranks),
+                              out.ctypes.data_as(_ip))
+    if rc != 0:
+        raise NdsmHipError(f"ndsm_hip_slab_plan failed with code {rc} (slabs thinner than the ghost depth?)")
+    return [dict(zip(SLAB_FIELDS, (int(v) for v in row))) for row in out]
+
+
+class World:
+    """Level 1 split into z-slabs.  rank >= 0: this process owns slab `rank` (RCCL);
+    rank < 0: loop-back, all slabs on this GPU.  Arrays are numpy (nz, ny, nx)."""
+
+    def __init__(self, nshape, mesh, bcs, nranks, rank=-1, ngrids=0, ms=5, ex_tol=1e-13, du_max=True,
+                 nmax_exact=10000, lib=None):
+        self.L = lib or load_library()
+        self.nshape = [int(v) for v in nshape]
+        ns = np.asarray(nshape, dtype=np.intc)
+        m = [_f64(v) for v in mesh]
+        self.h = ctypes.c_void_p()
+        rc = self.L.ndsm_hip_world_create(ns.ctypes.data_as(_ip), _d(m[0]), _d(m[1]), _d(m[2]), bcs.encode(),
+                                          int(ngrids), int(ms), float(ex_tol), 1 if du_max else 0, int(nmax_exact),
+                                          int(nranks), int(rank), ctypes.byref(self.h))
+        _check(rc, "ndsm_hip_world_create", self.L)
+        self.nlocal = self.L.ndsm_hip_world_nlocal(self.h)
+        self.slabs = []
+        for i in range(1, self.nlocal + 1):
+            info = np.zeros(12, dtype=np.intc)
+            _check(self.L.ndsm_hip_world_slab(self.h, i, info.ctypes.data_as(_ip)), "world_slab", self.L)
+            self.slabs.append(dict(zip(SLAB_FIELDS, (int(v) for v in info))))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.ndsm_hip_world_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, which, arr):
+        """arr: the GLOBAL field (nz, ny, nx); every local slab takes its window incl. ghosts"""
+        a = _f64(arr)
+        assert a.shape == tuple(self.nshape[::-1])
+        for i in range(1, self.nlocal + 1):
+            _check(self.L.ndsm_hip_world_upload(self.h, i, which, _d(a), 0, a.shape[0]), "world_upload", self.L)
+
+    def upload_window(self, ilocal, which, window, gz0):
+        """window: planes [gz0, gz0 + window.shape[0]) of the global field"""
+        a = _f64(window)
+        _check(self.L.ndsm_hip_world_upload(self.h, ilocal, which, _d(a), int(gz0), a.shape[0]), "world_upload", self.L)
+
+    def download(self, which, out=None):
+        """owned planes of every local slab -> (global-shaped array, filled where owned)"""
+        nx, ny, nz = self.nshape
+        if out is None:
+            out = np.full((nz, ny, nx), np.nan)
+        for i, sl in enumerate(self.slabs, start=1):
+            buf = np.empty((sl["z1"] - sl["z0"], ny, nx))
+            _check(self.L.ndsm_hip_world_download(self.h, i, which, _d(buf)), "world_download", self.L)
+            out[sl["z0"]:sl["z1"]] = buf
+        return out
+
+    def relax(self, n=1):
+        _check(self.L.ndsm_hip_world_relax(self.h, n), "world_relax", self.L)
+
+    def vcycle(self, n=1):
+        _check(self.L.ndsm_hip_world_vcycle(self.h, n), "world_vcycle", self.L)
+
+    def solve(self, vc_tol=1e-10, nmax=1024, hist_len=0):
+        du = ctypes.c_double(0)
+        nc = ctypes.c_int(0)
+        hist = np.zeros(max(hist_len, 1))
+        ierr = self.L.ndsm_hip_world_solve(self.h, float(vc_tol), int(nmax), ctypes.byref(du), ctypes.byref(nc),
+                                           _d(hist), int(hist_len))
+        if ierr >= 9000:
+            _check(ierr, "ndsm_hip_world_solve", self.L)
+        return ierr, du.value, nc.value, hist[:min(hist_len, nc.value)].copy()
+
+    def sync(self):
+        _check(self.L.ndsm_hip_sync(), "sync", self.L)
+
+    def timed(self, fn):
+        _check(self.L.ndsm_hip_timer_start(), "timer_start", self.L)
+        fn()
+        ms = ctypes.c_double(0)
+        _check(self.L.ndsm_hip_timer_stop(ctypes.byref(ms)), "timer_stop", self.L)
+        return ms.value
+
+
+def dist_unique_id(lib=None):
+    L = lib or load_library()
+    buf = ctypes.create_string_buffer(128)
+    _check(L.ndsm_hip_dist_unique_id(buf), "ndsm_hip_dist_unique_id", L)
+    return buf.raw
+
+
+def dist_init(rank, nranks, uid, lib=None):
+    L = lib or load_library()
+    _check(L.ndsm_hip_dist_init(int(rank), int(nranks), ctypes.c_char_p(uid)), "ndsm_hip_dist_init", L)
 
 
 def poisson_solve(u, rhs, mesh, bcs, ms=5, ex_tol=1e-13, du_max=True, nmax_exact=10000, vc_tol=1e-10, nmax=1024,

@@ -1,0 +1,129 @@
+// RCCL transport of the z-slab decomposition: point-to-point plane exchange
+// between z-neighbours and with rank 0, and the 2-value reduction of the
+// convergence metric.  One process per GPU; every call is enqueued on the
+// library stream, so it is ordered with the kernels without host waits.
+//
+// The reference has no distributed mode (shared-memory OpenMP only); this is
+// the xGMI-native counterpart SURVEY 8e specifies.  xGMI is point-to-point: a
+// z-slab chain uses one direct link per neighbour, so a halo exchange is a
+// grouped ncclSend/ncclRecv pair per neighbour - no ring collective is involved
+// in the data path.
+#include "common.hpp"
+
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+struct Dist {
+  bool up = false;
+  int rank = 0, size = 1;
+  ncclComm_t comm = nullptr;
+  double *d_red = nullptr;  // 2 doubles
+};
+Dist g_d;
+
+int nccl_fail(ncclResult_t r, const char *file, int line) {
+  return ndsm::fail(NDSMK_ENCCL, ncclGetErrorString(r), file, line);
+}
+
+}  // namespace
+
+#define NDSM_NCCL(call)                                                  \
+  do {                                                                   \
+    ncclResult_t r_ = (call);                                            \
+    if (r_ != ncclSuccess) return nccl_fail(r_, __FILE__, __LINE__);     \
+  } while (0)
+
+extern "C" {
+
+// 128 bytes, to be created on rank 0 and handed to every rank by the launcher
+// (bench.py / tests broadcast it through torch.distributed's gloo group).
+int ndsmk_dist_unique_id(void *out128) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId id;
+  NDSM_NCCL(ncclGetUniqueId(&id));
+  std::memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+
+int ndsmk_dist_init(int rank, int nranks, const void *id128) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(nranks >= 1 && rank >= 0 && rank < nranks);
+  if (g_d.up) return (g_d.rank == rank && g_d.size == nranks) ? 0
+                     : ndsm::fail(NDSMK_EARG, "RCCL communicator already initialised differently", __FILE__, __LINE__);
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  NDSM_NCCL(ncclCommInitRank(&g_d.comm, nranks, id, rank));
+  NDSM_HIP(hipMalloc((void **)&g_d.d_red, 2 * sizeof(double)));
+  g_d.rank = rank;
+  g_d.size = nranks;
+  g_d.up = true;
+  return 0;
+}
+
+int ndsmk_dist_finalize(void) {
+  if (!g_d.up) return 0;
+  (void)hipStreamSynchronize(ndsm::stream());
+  ncclCommDestroy(g_d.comm);
+  (void)hipFree(g_d.d_red);
+  g_d = Dist();
+  return 0;
+}
+
+// Which shared objects this library's HIP and RCCL calls are bound to.  A
+// process that also imports PyTorch holds a second ROCm stack (torch bundles its
+// own libamdhip64 / librccl); streams must never cross from one stack to the
+// other, so both answers have to name the same stack (tests check this).
+int ndsmk_bound_libs(char *buf, int len) {
+  Dl_info a, b;
+  const char *ha = "?", *hb = "?";
+  if (dladdr(reinterpret_cast<void *>(&hipStreamSynchronize), &a) && a.dli_fname) ha = a.dli_fname;
+  if (dladdr(reinterpret_cast<void *>(&ncclGetUniqueId), &b) && b.dli_fname) hb = b.dli_fname;
+  std::snprintf(buf, (size_t)len, "hip=%s;rccl=%s", ha, hb);
+  return 0;
+}
+
+int ndsmk_dist_rank(void) { return g_d.up ? g_d.rank : 0; }
+int ndsmk_dist_size(void) { return g_d.up ? g_d.size : 1; }
+
+int ndsmk_dist_group_start(void) {
+  NDSM_CHECK_ARG(g_d.up);
+  NDSM_NCCL(ncclGroupStart());
+  return 0;
+}
+int ndsmk_dist_group_end(void) {
+  NDSM_CHECK_ARG(g_d.up);
+  NDSM_NCCL(ncclGroupEnd());
+  return 0;
+}
+
+int ndsmk_dist_send(const double *p, size_t count, int peer) {
+  NDSM_CHECK_ARG(g_d.up && peer >= 0 && peer < g_d.size && peer != g_d.rank);
+  NDSM_NCCL(ncclSend(p, count, ncclDouble, peer, g_d.comm, ndsm::stream()));
+  return 0;
+}
+
+int ndsmk_dist_recv(double *p, size_t count, int peer) {
+  NDSM_CHECK_ARG(g_d.up && peer >= 0 && peer < g_d.size && peer != g_d.rank);
+  NDSM_NCCL(ncclRecv(p, count, ncclDouble, peer, g_d.comm, ndsm::stream()));
+  return 0;
+}
+
+// blocking: h_ms[0] <- max over ranks, h_ms[1] <- sum over ranks
+int ndsmk_dist_allreduce_max_sum(double *h_ms) {
+  NDSM_CHECK_ARG(g_d.up);
+  hipStream_t s = ndsm::stream();
+  NDSM_HIP(hipMemcpyAsync(g_d.d_red, h_ms, 2 * sizeof(double), hipMemcpyHostToDevice, s));
+  NDSM_NCCL(ncclAllReduce(g_d.d_red, g_d.d_red, 1, ncclDouble, ncclMax, g_d.comm, s));
+  NDSM_NCCL(ncclAllReduce(g_d.d_red + 1, g_d.d_red + 1, 1, ncclDouble, ncclSum, g_d.comm, s));
+  NDSM_HIP(hipMemcpyAsync(h_ms, g_d.d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  NDSM_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // extern "C"

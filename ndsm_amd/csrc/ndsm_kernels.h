@@ -40,8 +40,9 @@ typedef struct {
   int32_t lb[3], ub[3];  /* 0-based inclusive update bounds: shrink by one on 'D' faces */
   int32_t first_par;     /* colour of the first half-sweep: (i+j+k)&1 == first_par */
   int32_t all_neumann;   /* 1: subtract the mean after each sweep */
-  int32_t k0;            /* global z index of local plane 0 (z-slab runs), else 0 */
+  int32_t k0;            /* global z index of local plane 0 (z-slab runs; may be negative), else 0 */
   int32_t nzg;           /* global nz (== n[2] unless z-slab) */
+  int32_t zown0, zown1;  /* local planes [zown0, zown1) are owned (written); the rest are ghosts. 0, n[2] unless z-slab */
   double w[3];           /* 1/h^2 per dimension */
   double w1;             /* 1 / (2 (wx+wy+wz)) */
   double wc;             /* 2 (wx+wy+wz) */
@@ -61,6 +62,12 @@ typedef struct {
   const int32_t *rcnt[3]; /* number of contributing fine points */
   const double *rw[3];    /* rw[d][I*maxt[d] + t] = c2 = |h_c - |q_f - q_c||  (ndsm_interp.f90:279-280) */
   double w2[3];           /* h_f / h_c^2 per dimension (ndsm_interp.f90:229) */
+  /* z-slab windows (all zero / full range when not distributed).  The z tables are
+   * always indexed with GLOBAL plane numbers; the arrays may hold a window. */
+  int32_t f_k0;           /* global index of plane 0 of the fine array */
+  int32_t f_beg, f_cnt;   /* local fine planes [f_beg, f_beg+f_cnt) are written by prolong_add */
+  int32_t c_k0;           /* global index of plane 0 of the coarse array */
+  int32_t c_beg, c_cnt;   /* local coarse planes [c_beg, c_beg+c_cnt) are written by restrict */
 } ndsmk_xfer;
 
 /* ---- runtime ------------------------------------------------------- */

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void residual3(const double *__restrict__ u, c
   const int nx = g.n[0], ny = g.n[1];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
+  const int k = g.zown0 + blockIdx.z;  // owned planes only; ghosts of r are filled by the halo exchange
   if (i >= nx || j >= ny) return;
   const size_t c = (size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * (size_t)k);
   const int kg = k + g.k0;
@@ -67,7 +67,7 @@ extern "C" int ndsmk_residual(const ndsmk_grid *gp, const double *u, const doubl
   NDSM_CHECK_ARG(g.ndim == 2 || g.ndim == 3);
   NDSM_CHECK_ARG(g.n[0] >= 2 && g.n[1] >= 2 && (g.ndim == 2 ? g.n[2] == 1 : g.n[2] >= 2));
   dim3 block(64, 4, 1);
-  dim3 grid((g.n[0] + 63) / 64, (g.n[1] + 3) / 4, g.n[2]);
+  dim3 grid((g.n[0] + 63) / 64, (g.n[1] + 3) / 4, g.ndim == 3 ? g.zown1 - g.zown0 : 1);
   if (g.ndim == 3)
     hipLaunchKernelGGL(residual3, grid, block, 0, ndsm::stream(), u, rhs, r, g);
   else

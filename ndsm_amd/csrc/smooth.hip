@@ -84,6 +84,7 @@ extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, double *ualt, const 
   NDSM_CHECK_ARG(g.n[0] >= 2 && g.n[1] >= 2 && (g.ndim == 2 ? g.n[2] == 1 : g.n[2] >= 2));
   for (int d = 0; d < g.ndim; ++d) NDSM_CHECK_ARG(g.lb[d] >= 0 && g.ub[d] <= g.n[d] - 1);
   NDSM_CHECK_ARG(variant >= 0 && variant <= 2);
+  NDSM_CHECK_ARG(g.ndim == 2 || (g.zown0 >= 0 && g.zown1 <= g.n[2] && g.zown0 < g.zown1));
   const int64_t npts = (int64_t)g.n[0] * g.n[1] * g.n[2];
   hipStream_t s = ndsm::stream();
   const int mx = g.ub[0] - g.lb[0] + 1, my = g.ub[1] - g.lb[1] + 1, mz = g.ub[2] - g.lb[2] + 1;
@@ -105,6 +106,9 @@ extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, double *ualt, const 
           return ndsm::fail(NDSMK_EARG, "fused smoother does not support this level shape", __FILE__, __LINE__);
       }
       if (!done) {
+        if (g.zown0 != 0 || g.zown1 != g.n[2])
+          return ndsm::fail(NDSMK_EARG, "z-slab levels need the fused smoother (nx even, >= 16 x 16 x 8 owned)", __FILE__,
+                            __LINE__);
         const int half = (mx + 1) / 2;
         dim3 block(64, 4, 1);
         dim3 grid((half + 63) / 64, (my + 3) / 4, mz);

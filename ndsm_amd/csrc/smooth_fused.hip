@@ -110,8 +110,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 
   const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
   const int x0 = tx * TXI - 2, y0 = ty * TYI - 2;
-  const int zs = cz * pl.zc;
-  const int ze = min(zs + pl.zc, nz);
+  const int zs = g.zown0 + cz * pl.zc;
+  const int ze = min(zs + pl.zc, g.zown1);
   const int ks = max(zs - 2, 0);
   const int ke = min(ze + 1, nz - 1);
   const size_t sz = (size_t)nx * (size_t)ny;
@@ -269,10 +269,11 @@ int launch_cfg(const ndsmk_grid &g, const double *u, double *uout, const double 
   // z chunks: enough work items to fill the chip once, but chunks of >= 16 planes
   int nzc = (target_wgs + tiles - 1) / tiles;
   if (nzc < 1) nzc = 1;
-  int zc = (g.n[2] + nzc - 1) / nzc;
-  if (zc < 16) zc = 16 < g.n[2] ? 16 : g.n[2];
+  const int nzo = g.zown1 - g.zown0;  // owned planes
+  int zc = (nzo + nzc - 1) / nzc;
+  if (zc < 16) zc = 16 < nzo ? 16 : nzo;
   pl.zc = zc;
-  pl.nzc = (g.n[2] + zc - 1) / zc;
+  pl.nzc = (nzo + zc - 1) / zc;
   pl.nwork = tiles * pl.nzc;
   const int nblk = ((pl.nwork + 7) / 8) * 8;
   const size_t lds_bytes = sizeof(double) * 2 * TXH * TYH;
@@ -304,11 +305,11 @@ static int fused_cfg() {
 
 int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, bool *handled) {
   *handled = false;
-  if (!uout || g.ndim != 3 || (g.n[0] & 1) || g.n[0] < 16 || g.n[1] < 16 || g.n[2] < 16) return 0;
+  if (!uout || g.ndim != 3 || (g.n[0] & 1) || g.n[0] < 16 || g.n[1] < 16 || g.zown1 - g.zown0 < 8) return 0;
   // a z-streaming workgroup walks >= 16 planes serially: with fewer than ~one
   // workgroup per CU the sweep is latency bound and the two colour passes win
-  const int64_t npts = (int64_t)g.n[0] * g.n[1] * g.n[2];
-  if (npts < (int64_t)6 * 1024 * 1024) return 0;
+  const int64_t npts = (int64_t)g.n[0] * g.n[1] * (g.zown1 - g.zown0);
+  if (npts < (int64_t)6 * 1024 * 1024 && g.zown1 - g.zown0 == g.n[2]) return 0;
   // Tile choice measured on MI355X (scripts/tune_smoother.py): the sweep is bound
   // by fabric traffic (halo rows + chunk warm-up planes, ~1.3x compulsory), and
   // more, shorter chunks beat fewer, longer ones up to ~8 work items per CU.

@@ -26,6 +26,7 @@ struct XferDev {  // by-value kernel argument (pointers are device pointers)
   const int32_t *rlo[3], *rcnt[3];
   const double *rw[3];
   double w2[3];
+  int f_k0, f_beg, f_cnt, c_k0, c_beg, c_cnt;
 };
 
 template <int NDIM>
@@ -33,7 +34,8 @@ __global__ __launch_bounds__(256) void restrict_k(const double *__restrict__ f, 
                                                   double *__restrict__ u_c, XferDev x) {
   const int I = blockIdx.x * blockDim.x + threadIdx.x;
   const int J = blockIdx.y * blockDim.y + threadIdx.y;
-  const int K = blockIdx.z;
+  const int Kl = x.c_beg + (int)blockIdx.z;  // local coarse plane
+  const int K = Kl + x.c_k0;                  // its global index (the z tables are global)
   if (I >= x.nc[0] || J >= x.nc[1]) return;
   const int i0 = x.rlo[0][I], ni = x.rcnt[0][I];
   const int j0 = x.rlo[1][J], nj = x.rcnt[1][J];
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void restrict_k(const double *__restrict__ f, 
   const size_t sy = (size_t)x.nf[0], sz = (size_t)x.nf[0] * (size_t)x.nf[1];
   double fc = 0.0;
   if (NDIM == 3) {
-    const int k0 = x.rlo[2][K], nk = x.rcnt[2][K];
+    const int k0 = x.rlo[2][K] - x.f_k0, nk = x.rcnt[2][K];  // first tap as a local fine plane
     const double *cz = x.rw[2] + (size_t)K * x.maxt[2];
     for (int kk = 0; kk < nk; ++kk) {
       const double c2z = cz[kk];
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void restrict_k(const double *__restrict__ f, 
       }
     }
   }
-  const size_t c = (size_t)I + (size_t)x.nc[0] * ((size_t)J + (size_t)x.nc[1] * (size_t)K);
+  const size_t c = (size_t)I + (size_t)x.nc[0] * ((size_t)J + (size_t)x.nc[1] * (size_t)(NDIM == 3 ? Kl : 0));
   rhs_c[c] = fc;
   if (u_c) u_c[c] = 0.0;  // coarse correction starts from zero (ndsm_multigrid_core.f90:557-558)
 }
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void prolong_add_k(const double *__restrict__ 
                                                      XferDev x) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
+  const int k = x.f_beg + (int)blockIdx.z;  // local fine plane
   if (i >= x.nf[0] || j >= x.nf[1]) return;
   const int il = x.plo[0][i], jl = x.plo[1][j];
   const double wlx = x.pwl[0][i], whx = x.pwh[0][i];
@@ -86,8 +88,9 @@ __global__ __launch_bounds__(256) void prolong_add_k(const double *__restrict__ 
   const size_t sy = (size_t)x.nc[0], sz = (size_t)x.nc[0] * (size_t)x.nc[1];
   double v;
   if (NDIM == 3) {
-    const int kl = x.plo[2][k];
-    const double wlz = x.pwl[2][k], whz = x.pwh[2][k];
+    const int kgl = k + x.f_k0;               // global fine plane: index into the z tables
+    const int kl = x.plo[2][kgl] - x.c_k0;    // lower bracket as a local coarse plane
+    const double wlz = x.pwl[2][kgl], whz = x.pwh[2][kgl];
     const double *p = uc + (size_t)il + sy * (size_t)jl + sz * (size_t)kl;
     // fs(n): bit0 = upper x, bit1 = upper y, bit2 = upper z (ndsm_interp.f90:340-363)
     double f0 = p[0], f1 = p[1], f2 = p[sy], f3 = p[sy + 1];
@@ -124,6 +127,17 @@ int to_dev(const ndsmk_xfer *x, XferDev *d, int *ndim) {
     d->rw[a] = x->rw[a];
     d->w2[a] = x->w2[a];
   }
+  d->f_k0 = x->f_k0;
+  d->f_beg = x->f_beg;
+  d->f_cnt = x->f_cnt;
+  d->c_k0 = x->c_k0;
+  d->c_beg = x->c_beg;
+  d->c_cnt = x->c_cnt;
+  if (*ndim == 2) {
+    d->f_k0 = d->f_beg = d->c_k0 = d->c_beg = 0;
+    d->f_cnt = d->c_cnt = 1;
+  }
+  NDSM_CHECK_ARG(d->f_cnt >= 1 && d->c_cnt >= 1 && d->f_beg >= 0 && d->c_beg >= 0);
   for (int a = 0; a < *ndim; ++a) {
     NDSM_CHECK_ARG(x->nf[a] >= 2 && x->nc[a] >= 2 && x->maxt[a] >= 1);
     NDSM_CHECK_ARG(x->plo[a] && x->pwl[a] && x->pwh[a] && x->rlo[a] && x->rcnt[a] && x->rw[a]);
@@ -139,7 +153,7 @@ extern "C" int ndsmk_restrict(const ndsmk_xfer *x, const double *r_f, double *rh
   int ndim;
   if (int rc = to_dev(x, &d, &ndim)) return rc;
   dim3 block(32, 8, 1);
-  dim3 grid((d.nc[0] + 31) / 32, (d.nc[1] + 7) / 8, d.nc[2]);
+  dim3 grid((d.nc[0] + 31) / 32, (d.nc[1] + 7) / 8, d.c_cnt);
   if (ndim == 3)
     hipLaunchKernelGGL(restrict_k<3>, grid, block, 0, ndsm::stream(), r_f, rhs_c, u_c, d);
   else
@@ -154,7 +168,7 @@ extern "C" int ndsmk_prolong_add(const ndsmk_xfer *x, const double *u_c, double 
   int ndim;
   if (int rc = to_dev(x, &d, &ndim)) return rc;
   dim3 block(64, 4, 1);
-  dim3 grid((d.nf[0] + 63) / 64, (d.nf[1] + 3) / 4, d.nf[2]);
+  dim3 grid((d.nf[0] + 63) / 64, (d.nf[1] + 3) / 4, d.f_cnt);
   if (ndim == 3)
     hipLaunchKernelGGL(prolong_add_k<3>, grid, block, 0, ndsm::stream(), u_c, u_f, d);
   else

@@ -17,10 +17,26 @@ module ndsmh_cabi
   use, intrinsic :: iso_c_binding
   use, intrinsic :: iso_fortran_env, only: error_unit
   use ndsmh_iface
+  use ndsmh_grid, only: slab_t
   use ndsmh_mg
+  use ndsmh_world
   use ndsmh_vecpot
   implicit none
   private
+
+  interface
+    function ndsmk_dist_unique_id(out128) bind(c, name="ndsmk_dist_unique_id") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: out128
+      integer(c_int) :: rc
+    end function
+    function ndsmk_dist_init(rank, nranks, id128) bind(c, name="ndsmk_dist_init") result(rc)
+      import :: c_ptr, c_int
+      integer(c_int), value :: rank, nranks
+      type(c_ptr), value :: id128
+      integer(c_int) :: rc
+    end function
+  end interface
 
   interface
     function c_strlen(s) bind(c, name="strlen") result(n)
@@ -447,6 +463,188 @@ contains
     type(mg_solver), pointer :: s
     call c_f_pointer(handle, s)
     rc = mg_read_info(s, sweeps, unconverged)
+  end function
+
+  ! ---- z-slab decomposition over GPUs (SURVEY 8e) -----------------------
+
+  ! rank 0 creates the 128-byte RCCL id; the launcher hands it to every rank
+  function ndsm_hip_dist_unique_id(id128) bind(c, name="ndsm_hip_dist_unique_id") result(rc)
+    type(c_ptr), value :: id128
+    integer(c_int) :: rc
+    rc = ndsmk_dist_unique_id(id128)
+  end function
+
+  function ndsm_hip_dist_init(rank, nranks, id128) bind(c, name="ndsm_hip_dist_init") result(rc)
+    integer(c_int), value :: rank, nranks
+    type(c_ptr), value :: id128
+    integer(c_int) :: rc
+    rc = ndsmk_dist_init(rank, nranks, id128)
+  end function
+
+  ! The slab plan every rank derives (pure host arithmetic, no GPU needed).
+  ! out(12, nranks): rank, z0, z1, g, nloc, k0, ck0, ck1, pk0, pk1, cb0, cb1
+  function ndsm_hip_slab_plan(nshape, x, y, z, ngrids, nranks, out) bind(c, name="ndsm_hip_slab_plan") result(rc)
+    integer(c_int), intent(in) :: nshape(3)
+    integer(c_int), value :: ngrids, nranks
+    type(c_ptr), value :: x, y, z
+    integer(c_int), intent(out) :: out(12, nranks)
+    integer(c_int) :: rc
+    real(c_double), pointer :: qx(:), qy(:), qz(:)
+    type(slab_t), allocatable :: plan(:)
+    integer(c_int32_t) :: n3(3)
+    integer :: r
+    n3 = nshape
+    call c_f_pointer(x, qx, [n3(1)])
+    call c_f_pointer(y, qy, [n3(2)])
+    call c_f_pointer(z, qz, [n3(3)])
+    rc = world_plan_only(n3, qx, qy, qz, int(ngrids), int(nranks), plan)
+    if (rc /= 0) return
+    do r = 0, nranks - 1
+      out(:, r + 1) = [plan(r)%rank, plan(r)%z0, plan(r)%z1, plan(r)%g, plan(r)%nloc, plan(r)%k0, plan(r)%ck0, &
+                       plan(r)%ck1, plan(r)%pk0, plan(r)%pk1, plan(r)%cb0, plan(r)%cb1]
+    end do
+  end function
+
+  ! rank >= 0: this process holds slab `rank` (RCCL transport, after ndsm_hip_dist_init);
+  ! rank < 0 : loop-back world, all nranks slabs on this GPU (verification)
+  function ndsm_hip_world_create(nshape, x, y, z, bcs, ngrids, ms, ex_tol, du_max, nmax_exact, nranks, rank, handle) &
+      bind(c, name="ndsm_hip_world_create") result(rc)
+    integer(c_int), intent(in) :: nshape(3)
+    integer(c_int), value :: ngrids, ms, du_max, nmax_exact, nranks, rank
+    real(c_double), value :: ex_tol
+    type(c_ptr), value :: x, y, z
+    character(kind=c_char), intent(in) :: bcs(6)
+    type(c_ptr), intent(out) :: handle
+    integer(c_int) :: rc
+    type(mg_world), pointer :: w
+    real(c_double), pointer :: qx(:), qy(:), qz(:)
+    integer(c_int32_t) :: n3(3)
+    character(len=1) :: bc(6)
+    integer :: d, i
+    handle = c_null_ptr
+    n3 = nshape
+    call c_f_pointer(x, qx, [n3(1)])
+    call c_f_pointer(y, qy, [n3(2)])
+    call c_f_pointer(z, qz, [n3(3)])
+    do d = 1, 6
+      bc(d) = bcs(d)
+    end do
+    rc = ndsmk_init(-1_c_int)
+    if (rc /= 0) return
+    allocate (w)
+    rc = world_create(w, n3, qx, qy, qz, bc, int(ngrids), int(nranks), int(rank))
+    if (rc /= 0) then
+      call world_destroy(w)
+      deallocate (w)
+      return
+    end if
+    do i = 1, w%nlocal
+      w%loc(i)%ms = ms; w%loc(i)%ex_tol = ex_tol; w%loc(i)%use_max = (du_max == 1)
+      w%loc(i)%nmax_exact = nmax_exact
+    end do
+    handle = c_loc(w)
+  end function
+
+  function ndsm_hip_world_destroy(handle) bind(c, name="ndsm_hip_world_destroy") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int) :: rc
+    type(mg_world), pointer :: w
+    rc = 0
+    if (.not. c_associated(handle)) return
+    call c_f_pointer(handle, w)
+    call world_destroy(w)
+    deallocate (w)
+  end function
+
+  function ndsm_hip_world_nlocal(handle) bind(c, name="ndsm_hip_world_nlocal") result(n)
+    type(c_ptr), value :: handle
+    integer(c_int) :: n
+    type(mg_world), pointer :: w
+    call c_f_pointer(handle, w)
+    n = w%nlocal
+  end function
+
+  ! info(12) of local slab ilocal (1-based): same fields as ndsm_hip_slab_plan
+  function ndsm_hip_world_slab(handle, ilocal, info) bind(c, name="ndsm_hip_world_slab") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int), value :: ilocal
+    integer(c_int), intent(out) :: info(12)
+    integer(c_int) :: rc
+    type(mg_world), pointer :: w
+    call c_f_pointer(handle, w)
+    rc = NDSMK_EARG
+    if (ilocal < 1 .or. ilocal > w%nlocal) return
+    associate (p => w%loc(ilocal)%sl)
+      info = [p%rank, p%z0, p%z1, p%g, p%nloc, p%k0, p%ck0, p%ck1, p%pk0, p%pk1, p%cb0, p%cb1]
+    end associate
+    rc = 0
+  end function
+
+  ! host points at global plane gz0 of an (nx,ny,*) array holding nplanes planes
+  function ndsm_hip_world_upload(handle, ilocal, which, host, gz0, nplanes) bind(c, name="ndsm_hip_world_upload") &
+      result(rc)
+    type(c_ptr), value :: handle, host
+    integer(c_int), value :: ilocal, which, gz0, nplanes
+    integer(c_int) :: rc
+    type(mg_world), pointer :: w
+    call c_f_pointer(handle, w)
+    rc = world_upload(w, int(ilocal), int(which), host, int(gz0), int(nplanes))
+  end function
+
+  ! host receives the slab's owned planes [z0, z1)
+  function ndsm_hip_world_download(handle, ilocal, which, host) bind(c, name="ndsm_hip_world_download") result(rc)
+    type(c_ptr), value :: handle, host
+    integer(c_int), value :: ilocal, which
+    integer(c_int) :: rc
+    type(mg_world), pointer :: w
+    call c_f_pointer(handle, w)
+    rc = world_download(w, int(ilocal), int(which), host)
+  end function
+
+  function ndsm_hip_world_relax(handle, nsweeps) bind(c, name="ndsm_hip_world_relax") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int), value :: nsweeps
+    integer(c_int) :: rc
+    type(mg_world), pointer :: w
+    call c_f_pointer(handle, w)
+    rc = world_relax(w, int(nsweeps))
+  end function
+
+  function ndsm_hip_world_vcycle(handle, ncycles) bind(c, name="ndsm_hip_world_vcycle") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int), value :: ncycles
+    integer(c_int) :: rc
+    type(mg_world), pointer :: w
+    integer :: i
+    call c_f_pointer(handle, w)
+    rc = 0
+    do i = 1, ncycles
+      rc = world_vcycle(w)
+      if (rc /= 0) return
+    end do
+  end function
+
+  function ndsm_hip_world_solve(handle, vc_tol, nmax, du_last, ncycles, hist, hist_len) &
+      bind(c, name="ndsm_hip_world_solve") result(ierr)
+    type(c_ptr), value :: handle, hist
+    real(c_double), value :: vc_tol
+    integer(c_int), value :: nmax, hist_len
+    real(c_double), intent(out) :: du_last
+    integer(c_int), intent(out) :: ncycles
+    integer(c_int) :: ierr
+    type(mg_world), pointer :: w
+    real(c_double), pointer :: hh(:)
+    integer :: nc, ie
+    integer(c_int) :: rc
+    call c_f_pointer(handle, w)
+    if (c_associated(hist) .and. hist_len > 0) then
+      call c_f_pointer(hist, hh, [hist_len])
+      rc = world_solve(w, vc_tol, int(nmax), du_last, nc, ie, hh)
+    else
+      rc = world_solve(w, vc_tol, int(nmax), du_last, nc, ie)
+    end if
+    ncycles = nc
+    ierr = merge(rc, int(ie, c_int), rc /= 0)
   end function
 
 end module ndsmh_cabi

@@ -24,8 +24,9 @@ module ndsmh_grid
   implicit none
   private
 
-  public :: axis_t, level_t, axis_xfer_t
+  public :: axis_t, level_t, axis_xfer_t, slab_t
   public :: ndsm_level_count, build_levels, build_axis_xfer, fill_grid_desc, locate_uniform
+  public :: plan_slabs, apply_slab_window
 
   ! one coordinate axis of one level
   type :: axis_t
@@ -50,7 +51,94 @@ module ndsmh_grid
     real(wp) :: w2 = 0                               ! h_f / h_c**2
   end type
 
+  ! z-slab of level 1 owned by one rank (all plane indices GLOBAL and 0-based,
+  ! ranges half open).  The reference has no distributed mode; this is the
+  ! decomposition of SURVEY 8e.
+  type :: slab_t
+    integer :: rank = 0, nranks = 1
+    integer :: z0 = 0, z1 = 0        ! owned fine planes [z0, z1)
+    integer :: g = 2                 ! ghost planes on each side of the local arrays
+    integer :: nloc = 0              ! z1 - z0 + 2 g : planes of the local level-1 arrays
+    integer :: k0 = 0                ! z0 - g : global index of local plane 0 (may be < 0)
+    integer :: ck0 = 0, ck1 = 0      ! coarse planes this rank computes in the restriction
+    integer :: pk0 = 0, pk1 = 0      ! coarse planes this rank reads in the prolongation
+    integer :: cb0 = 0, cb1 = 0      ! window of the local coarse buffer = union of the two
+  end type
+
 contains
+
+  ! Split nz fine planes over nranks slabs and derive, from the level 1 -> 2 z
+  ! tables, who restricts which coarse plane, which coarse planes each rank needs
+  ! back, and the ghost depth that makes both possible:
+  !   * owned planes: balanced contiguous split;
+  !   * coarse plane K is computed by the owner of its middle tap, so every rank
+  !     gets one contiguous range and the ranges tile [0, nzc);
+  !   * ghost depth = max(2, deepest tap outside the owner's slab): 2 planes feed
+  !     the fused smoother's red/black pipeline, the rest the restriction.
+  ! ok = .false. if some slab would own fewer planes than the ghost depth.
+  subroutine plan_slabs(nz, nzc, tz, nranks, plan, ok)
+    integer, intent(in) :: nz, nzc, nranks
+    type(axis_xfer_t), intent(in) :: tz
+    type(slab_t), allocatable, intent(out) :: plan(:)
+    logical, intent(out) :: ok
+    integer :: r, kc, m, own, depth, lo, hi
+
+    ok = .false.
+    if (nranks < 1 .or. nz < nranks) return
+    allocate (plan(0:nranks - 1))
+    do r = 0, nranks - 1
+      plan(r)%rank = r; plan(r)%nranks = nranks
+      plan(r)%z0 = int((int(r, ik) * nz) / nranks)
+      plan(r)%z1 = int((int(r + 1, ik) * nz) / nranks)
+      plan(r)%ck0 = nzc; plan(r)%ck1 = 0
+    end do
+    depth = 2
+    do kc = 0, nzc - 1
+      lo = tz%rlo(kc + 1); hi = lo + tz%rcnt(kc + 1)      ! fine taps [lo, hi)
+      m = lo + tz%rcnt(kc + 1) / 2
+      own = nranks - 1
+      do r = 0, nranks - 1
+        if (m >= plan(r)%z0 .and. m < plan(r)%z1) own = r
+      end do
+      plan(own)%ck0 = min(plan(own)%ck0, kc)
+      plan(own)%ck1 = max(plan(own)%ck1, kc + 1)
+      depth = max(depth, plan(own)%z0 - lo, hi - plan(own)%z1)
+    end do
+    do r = 0, nranks - 1
+      if (plan(r)%ck1 <= plan(r)%ck0) then      ! owns no coarse plane
+        plan(r)%ck0 = 0; plan(r)%ck1 = 0
+      end if
+      plan(r)%g = depth
+      plan(r)%nloc = plan(r)%z1 - plan(r)%z0 + 2 * depth
+      plan(r)%k0 = plan(r)%z0 - depth
+      plan(r)%pk0 = tz%plo(plan(r)%z0 + 1)
+      plan(r)%pk1 = tz%plo(plan(r)%z1) + 2
+      plan(r)%cb0 = plan(r)%pk0; plan(r)%cb1 = plan(r)%pk1
+      if (plan(r)%ck1 > plan(r)%ck0) then
+        plan(r)%cb0 = min(plan(r)%cb0, plan(r)%ck0)
+        plan(r)%cb1 = max(plan(r)%cb1, plan(r)%ck1)
+      end if
+      if (plan(r)%z1 - plan(r)%z0 < max(depth, 8)) return
+    end do
+    ok = .true.
+  end subroutine
+
+  ! Turn the (global) descriptor of level 1 into the descriptor of one slab:
+  ! local plane count, global offset for colouring / mirror faces, owned range
+  ! and the physical update bounds clipped to the local window.
+  subroutine apply_slab_window(lv, sl)
+    type(level_t), intent(inout) :: lv
+    type(slab_t), intent(in) :: sl
+    integer :: lbg, ubg
+    lbg = lv%g%lb(3); ubg = lv%g%ub(3)              ! global bounds from fill_grid_desc
+    lv%g%n(3) = sl%nloc
+    lv%g%k0 = sl%k0
+    lv%g%nzg = lv%n(3)
+    lv%g%zown0 = sl%g
+    lv%g%zown1 = sl%g + (sl%z1 - sl%z0)
+    lv%g%lb(3) = max(lbg - sl%k0, 0)
+    lv%g%ub(3) = min(ubg - sl%k0, sl%nloc - 1)
+  end subroutine
 
   ! Number of grids the reference would use for this (fine) shape.
   pure function ndsm_level_count(ndim, nshape) result(ng)
@@ -139,6 +227,8 @@ contains
     lv%g%all_neumann = merge(1, 0, all(bcs(1:2 * ndim) == 'N'))
     lv%g%k0 = 0
     lv%g%nzg = lv%n(3)
+    lv%g%zown0 = 0
+    lv%g%zown1 = lv%n(3)
   end subroutine
 
   ! Bracket of coordinate `c` in the uniform axis q(1:nq): returns the 1-based

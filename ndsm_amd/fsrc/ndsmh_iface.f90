@@ -25,6 +25,7 @@ module ndsmh_iface
     integer(c_int32_t) :: all_neumann = 0
     integer(c_int32_t) :: k0 = 0
     integer(c_int32_t) :: nzg = 1
+    integer(c_int32_t) :: zown0 = 0, zown1 = 1
     real(c_double) :: w(3) = 0
     real(c_double) :: w1 = 0
     real(c_double) :: wc = 0
@@ -35,6 +36,8 @@ module ndsmh_iface
     type(c_ptr) :: plo(3), pwl(3), pwh(3)
     type(c_ptr) :: rlo(3), rcnt(3), rw(3)
     real(c_double) :: w2(3) = 0
+    integer(c_int32_t) :: f_k0 = 0, f_beg = 0, f_cnt = 1
+    integer(c_int32_t) :: c_k0 = 0, c_beg = 0, c_cnt = 1
   end type
 
   interface

@@ -26,7 +26,7 @@ module ndsmh_mg
 
   public :: mg_solver, mg_create, mg_destroy, mg_vcycle, mg_solve
   public :: mg_set_u, mg_set_rhs, mg_get_u, mg_zero_rhs, mg_level_ptr, mg_op, mg_read_info
-  public :: mg_set_bcs, mg_export_u, mg_reset_info
+  public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
   public :: MG_BUF_U, MG_BUF_RHS, MG_BUF_R
   public :: MG_OP_RELAX, MG_OP_RESIDUAL, MG_OP_RESTRICT, MG_OP_PROLONG, MG_OP_EXACT, MG_OP_RELAX_COLOR, &
             MG_OP_RELAX_FUSED
@@ -61,6 +61,13 @@ module ndsmh_mg
     type(c_ptr) :: scr = c_null_ptr      ! coarsest-level scratch
     type(c_ptr) :: info = c_null_ptr     ! 2 x int64 on the device: exact sweeps, unconverged coarse solves
     integer(ik) :: vcycles_done = 0
+    integer(ik) :: npts1 = 0             ! elements of the level-1 device arrays (local window if z-slab)
+    ! ---- z-slab mode (level 1 distributed, SURVEY 8e); unused otherwise
+    logical :: slab = .false.
+    logical :: has_coarse = .true.       ! levels >= 2 live here (rank 0 only when distributed)
+    type(slab_t) :: sl
+    type(c_ptr) :: cbuf = c_null_ptr     ! window [cb0, cb1) of level-2 planes: restriction out / prolongation in
+    integer(ik) :: plane1 = 0, plane2 = 0  ! elements per z-plane of level 1 / level 2
   end type
 
 contains
@@ -68,13 +75,14 @@ contains
   ! ------------------------------------------------------------------
   ! construction
   ! ------------------------------------------------------------------
-  function mg_create(s, ndim, nshape, qx, qy, qz, bcs, ngrids_req) result(rc)
+  function mg_create(s, ndim, nshape, qx, qy, qz, bcs, ngrids_req, slab) result(rc)
     type(mg_solver), intent(out) :: s
     integer, intent(in) :: ndim
     integer(c_int32_t), intent(in) :: nshape(3)
     real(wp), intent(in) :: qx(:), qy(:), qz(:)
     character(len=1), intent(in) :: bcs(:)
     integer, intent(in) :: ngrids_req          ! <= 0: the reference's rule
+    type(slab_t), intent(in), optional :: slab ! this rank's z-slab of level 1 (distributed runs)
     integer(c_int) :: rc
     integer :: l, d
     integer(c_size_t) :: nbytes
@@ -101,27 +109,56 @@ contains
     do l = 1, s%ngrids
       call fill_grid_desc(ndim, s%lev(l), s%bcs)
     end do
+    s%npts1 = s%lev(1)%npts
+    s%plane1 = int(s%lev(1)%n(1), ik) * int(s%lev(1)%n(2), ik)
+    if (s%ngrids >= 2) s%plane2 = int(s%lev(2)%n(1), ik) * int(s%lev(2)%n(2), ik)
+    if (present(slab)) then
+      rc = NDSMK_EARG
+      if (ndim /= 3 .or. s%ngrids < 2) return
+      s%slab = .true.
+      s%sl = slab
+      s%has_coarse = (slab%rank == 0)
+      call apply_slab_window(s%lev(1), s%sl)
+      s%npts1 = s%plane1 * int(s%sl%nloc, ik)
+    end if
 
     allocate (s%dl(s%ngrids))
     do l = 1, s%ngrids
-      nbytes = int(s%lev(l)%npts, c_size_t) * R8
+      if (l >= 2 .and. .not. s%has_coarse) cycle
+      nbytes = int(merge(s%npts1, s%lev(l)%npts, l == 1), c_size_t) * R8
       rc = ndsmk_alloc(s%dl(l)%u, nbytes); if (rc /= 0) return
       rc = ndsmk_alloc(s%dl(l)%rhs, nbytes); if (rc /= 0) return
       rc = ndsmk_alloc(s%dl(l)%ualt, nbytes); if (rc /= 0) return
       rc = ndsmk_fill0(s%dl(l)%u, nbytes); if (rc /= 0) return
+      rc = ndsmk_fill0(s%dl(l)%ualt, nbytes); if (rc /= 0) return
       rc = ndsmk_fill0(s%dl(l)%rhs, nbytes); if (rc /= 0) return
     end do
-    nbytes = int(s%lev(1)%npts, c_size_t) * R8
+    nbytes = int(s%npts1, c_size_t) * R8
+    ! the residual scratch also serves level 2 (rank 0 of a z-slab run: the slab may be smaller)
+    if (s%slab .and. s%has_coarse) nbytes = max(nbytes, int(s%lev(2)%npts, c_size_t) * R8)
     rc = ndsmk_alloc(s%r, nbytes); if (rc /= 0) return
+    rc = ndsmk_fill0(s%r, nbytes); if (rc /= 0) return
     rc = ndsmk_alloc(s%prev, nbytes); if (rc /= 0) return
+    if (s%slab) then
+      nbytes = int(s%plane2, c_size_t) * int(max(s%sl%cb1 - s%sl%cb0, 1), c_size_t) * R8
+      rc = ndsmk_alloc(s%cbuf, nbytes); if (rc /= 0) return
+      rc = ndsmk_fill0(s%cbuf, nbytes); if (rc /= 0) return
+    end if
     rc = ndsmk_alloc(s%scr, int(s%lev(s%ngrids)%npts, c_size_t) * R8); if (rc /= 0) return
     rc = ndsmk_alloc(s%info, 16_c_size_t); if (rc /= 0) return
     rc = ndsmk_fill0(s%info, 16_c_size_t); if (rc /= 0) return
 
     allocate (s%xf(max(s%ngrids - 1, 0)))
     do l = 1, s%ngrids - 1
+      if (l >= 2 .and. .not. s%has_coarse) cycle
       rc = upload_xfer(s, l); if (rc /= 0) return
     end do
+    if (s%slab) then      ! the level-1 arrays are a window of the global planes
+      s%xf(1)%x%f_k0 = s%sl%k0
+      s%xf(1)%x%f_beg = s%sl%g
+      s%xf(1)%x%f_cnt = s%sl%z1 - s%sl%z0
+      s%xf(1)%x%c_k0 = s%sl%cb0
+    end if
     rc = 0
   end function
 
@@ -157,6 +194,8 @@ contains
     s%xf(l)%x%nc = s%lev(l + 1)%n
     s%xf(l)%x%maxt = 1
     s%xf(l)%x%w2 = 0
+    s%xf(l)%x%f_k0 = 0; s%xf(l)%x%f_beg = 0; s%xf(l)%x%f_cnt = s%lev(l)%n(3)
+    s%xf(l)%x%c_k0 = 0; s%xf(l)%x%c_beg = 0; s%xf(l)%x%c_cnt = s%lev(l + 1)%n(3)
     do d = 1, 3
       s%xf(l)%x%plo(d) = c_null_ptr; s%xf(l)%x%pwl(d) = c_null_ptr; s%xf(l)%x%pwh(d) = c_null_ptr
       s%xf(l)%x%rlo(d) = c_null_ptr; s%xf(l)%x%rcnt(d) = c_null_ptr; s%xf(l)%x%rw(d) = c_null_ptr
@@ -205,6 +244,7 @@ contains
     do l = 1, s%ngrids
       call fill_grid_desc(s%ndim, s%lev(l), s%bcs)
     end do
+    if (s%slab) call apply_slab_window(s%lev(1), s%sl)
     rc = 0
   end function
 
@@ -213,7 +253,7 @@ contains
     type(mg_solver), intent(in) :: s
     type(c_ptr), intent(in) :: d_dst
     integer(c_int) :: rc
-    rc = ndsmk_d2d(d_dst, s%dl(1)%u, int(s%lev(1)%npts, c_size_t) * R8)
+    rc = ndsmk_d2d(d_dst, s%dl(1)%u, int(s%npts1, c_size_t) * R8)
   end function
 
   function mg_reset_info(s) result(rc)
@@ -244,6 +284,7 @@ contains
     rc = ndsmk_free(s%prev); s%prev = c_null_ptr
     rc = ndsmk_free(s%scr); s%scr = c_null_ptr
     rc = ndsmk_free(s%info); s%info = c_null_ptr
+    rc = ndsmk_free(s%cbuf); s%cbuf = c_null_ptr
     if (allocated(s%lev)) deallocate (s%lev)
     s%ngrids = 0
   end subroutine
@@ -255,27 +296,27 @@ contains
     type(mg_solver), intent(inout) :: s
     type(c_ptr), intent(in) :: h_u
     integer(c_int) :: rc
-    rc = ndsmk_h2d(s%dl(1)%u, h_u, int(s%lev(1)%npts, c_size_t) * R8)
+    rc = ndsmk_h2d(s%dl(1)%u, h_u, int(s%npts1, c_size_t) * R8)
   end function
 
   function mg_set_rhs(s, h_rhs) result(rc)
     type(mg_solver), intent(inout) :: s
     type(c_ptr), intent(in) :: h_rhs
     integer(c_int) :: rc
-    rc = ndsmk_h2d(s%dl(1)%rhs, h_rhs, int(s%lev(1)%npts, c_size_t) * R8)
+    rc = ndsmk_h2d(s%dl(1)%rhs, h_rhs, int(s%npts1, c_size_t) * R8)
   end function
 
   function mg_zero_rhs(s) result(rc)
     type(mg_solver), intent(inout) :: s
     integer(c_int) :: rc
-    rc = ndsmk_fill0(s%dl(1)%rhs, int(s%lev(1)%npts, c_size_t) * R8)
+    rc = ndsmk_fill0(s%dl(1)%rhs, int(s%npts1, c_size_t) * R8)
   end function
 
   function mg_get_u(s, h_u) result(rc)
     type(mg_solver), intent(inout) :: s
     type(c_ptr), intent(in) :: h_u
     integer(c_int) :: rc
-    rc = ndsmk_d2h(h_u, s%dl(1)%u, int(s%lev(1)%npts, c_size_t) * R8)
+    rc = ndsmk_d2h(h_u, s%dl(1)%u, int(s%npts1, c_size_t) * R8)
   end function
 
   ! device pointer + element count of a level buffer (tests, bench)
@@ -286,7 +327,8 @@ contains
     type(c_ptr) :: p
     p = c_null_ptr; npts = 0
     if (level < 1 .or. level > s%ngrids) return
-    npts = s%lev(level)%npts
+    if (level >= 2 .and. .not. s%has_coarse) return
+    npts = merge(s%npts1, s%lev(level)%npts, level == 1)
     select case (which)
     case (MG_BUF_U); p = s%dl(level)%u
     case (MG_BUF_RHS); p = s%dl(level)%rhs
@@ -317,6 +359,8 @@ contains
     type(c_ptr) :: tmp
     rc = NDSMK_EARG
     if (level < 1 .or. level > s%ngrids) return
+    if (level >= 2 .and. .not. s%has_coarse) return
+    if (s%slab .and. level == 1 .and. (op == MG_OP_RESTRICT .or. op == MG_OP_PROLONG)) return  ! mg_slab_* instead
     select case (op)
     case (MG_OP_RELAX, MG_OP_RELAX_COLOR, MG_OP_RELAX_FUSED)
       variant = merge(0, merge(1, 2, op == MG_OP_RELAX_COLOR), op == MG_OP_RELAX)
@@ -347,10 +391,21 @@ contains
   function mg_vcycle(s) result(rc)
     type(mg_solver), intent(inout) :: s
     integer(c_int) :: rc
+    rc = mg_vcycle_from(s, 1)
+    if (rc == 0) s%vcycles_done = s%vcycles_done + 1
+  end function
+
+  ! The V-cycle with level `ltop` as its finest grid (ltop = 1: the whole cycle;
+  ! ltop = 2: the part a z-slab run executes on rank 0 between the distributed
+  ! restriction and prolongation of level 1).
+  function mg_vcycle_from(s, ltop) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer, intent(in) :: ltop
+    integer(c_int) :: rc
     integer :: l
 
     ! descend: pre-smooth, residual, restrict (fine_to_coarse, :482-560)
-    do l = 1, s%ngrids - 1
+    do l = ltop, s%ngrids - 1
       rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
       rc = mg_op(s, MG_OP_RESIDUAL, l, 1); if (rc /= 0) return
       rc = mg_op(s, MG_OP_RESTRICT, l, 1); if (rc /= 0) return
@@ -361,13 +416,34 @@ contains
 
     ! ascend: smooth the coarse problem, interpolate + correct, post-smooth
     ! (coarse_to_fine, :593-684)
-    do l = s%ngrids, 2, -1
+    do l = s%ngrids, ltop + 1, -1
       rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
       rc = mg_op(s, MG_OP_PROLONG, l - 1, 1); if (rc /= 0) return
       rc = mg_op(s, MG_OP_RELAX, l - 1, s%ms); if (rc /= 0) return
     end do
-    s%vcycles_done = s%vcycles_done + 1
     rc = 0
+  end function
+
+  ! z-slab level 1: restrict the slab's residual into its window of coarse planes
+  ! [ck0, ck1) of cbuf (the planes are shipped to rank 0 by the caller)
+  function mg_slab_restrict(s) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer(c_int) :: rc
+    type(ndsmk_xfer) :: x
+    rc = 0
+    if (s%sl%ck1 <= s%sl%ck0) return
+    x = s%xf(1)%x
+    x%c_k0 = s%sl%cb0
+    x%c_beg = s%sl%ck0 - s%sl%cb0
+    x%c_cnt = s%sl%ck1 - s%sl%ck0
+    rc = ndsmk_restrict(x, s%r, s%cbuf, c_null_ptr)
+  end function
+
+  ! z-slab level 1: u += P (coarse planes [pk0, pk1) received into cbuf)
+  function mg_slab_prolong(s) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer(c_int) :: rc
+    rc = ndsmk_prolong_add(s%xf(1)%x, s%cbuf, s%dl(1)%u)
   end function
 
   ! ------------------------------------------------------------------
@@ -390,14 +466,14 @@ contains
     ncycles = 0
     ierr = 1
     ! the caller's array is the "previous iterate" of the first comparison (:122)
-    rc = ndsmk_d2d(s%prev, s%dl(1)%u, int(s%lev(1)%npts, c_size_t) * R8); if (rc /= 0) return
+    rc = ndsmk_d2d(s%prev, s%dl(1)%u, int(s%npts1, c_size_t) * R8); if (rc /= 0) return
     do it = 1, nmax
       rc = mg_vcycle(s); if (rc /= 0) return
-      rc = ndsmk_diff_metrics(s%dl(1)%u, s%prev, s%lev(1)%npts, 1_c_int, met); if (rc /= 0) return
+      rc = ndsmk_diff_metrics(s%dl(1)%u, s%prev, s%npts1, 1_c_int, met); if (rc /= 0) return
       if (s%use_max) then
         du = met(1)
       else
-        du = met(2) / real(s%lev(1)%npts, wp)
+        du = met(2) / real(s%npts1, wp)
       end if
       ncycles = it
       if (present(hist)) then

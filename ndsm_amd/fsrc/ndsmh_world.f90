@@ -1,0 +1,463 @@
+! libndsm_hip - z-slab decomposition of the finest level across GPUs (SURVEY 8e,
+! BASELINE config 4): one process per GPU, level 1 split along z (x-y planes are
+! contiguous in Fortran order), levels >= 2 on rank 0.
+!
+! The reference has no distributed mode; what must be preserved is its
+! ARITHMETIC: a distributed V-cycle returns the same bits as the single-GPU
+! one (tests/test_gpu_parity.py::test_slab_world_bitwise, loop-back mode).
+!
+! Per V-cycle, on the library stream, no host waits:
+!   level 1 down : ms x { ghost exchange of u (2 planes per neighbour) ; fused
+!                  red+black sweep of the owned planes }      - ONE exchange per
+!                  full sweep: the kernel's z pipeline recomputes the red update
+!                  of the first ghost plane, so the two exchanges per sweep of a
+!                  colour-by-colour scheme collapse into one of twice the depth;
+!                  exchange u ; residual ; exchange r (restriction taps reach up
+!                  to g planes into the neighbour) ; restrict the coarse planes
+!                  whose middle tap this rank owns ; ship them to rank 0
+!   levels >= 2  : rank 0 runs the rest of the V-cycle (mg_vcycle_from(2)) and the
+!                  ms pre-prolongation sweeps of level 2
+!   level 1 up   : rank 0 ships each rank the coarse planes its slab interpolates
+!                  from ; u += P u_c ; ms x { exchange ; sweep }
+! Convergence  : local max / sum of |du| over owned planes, one 2-value
+!                all-reduce; every rank takes the same decision.
+!
+! Transport: a "world" holds the slabs that live in THIS process.  Production:
+! one slab per process, neighbours reached with RCCL send/recv (xGMI).  Loop-back
+! (rank = -1 at creation): all slabs in one process on one GPU, neighbours
+! reached with device-to-device copies - the same driver code, used to verify
+! the decomposition bit for bit on a single GPU.
+module ndsmh_world
+
+  use, intrinsic :: iso_c_binding
+  use ndsmh_iface
+  use ndsmh_grid
+  use ndsmh_mg
+  implicit none
+  private
+
+  public :: mg_world, world_create, world_destroy, world_vcycle, world_solve, world_relax
+  public :: world_upload, world_download, world_plan_only
+
+  interface
+    function ndsmk_dist_size() bind(c, name="ndsmk_dist_size") result(n)
+      import :: c_int
+      integer(c_int) :: n
+    end function
+    function ndsmk_dist_rank() bind(c, name="ndsmk_dist_rank") result(n)
+      import :: c_int
+      integer(c_int) :: n
+    end function
+    function ndsmk_dist_group_start() bind(c, name="ndsmk_dist_group_start") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
+    function ndsmk_dist_group_end() bind(c, name="ndsmk_dist_group_end") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
+    function ndsmk_dist_send(p, count, peer) bind(c, name="ndsmk_dist_send") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: p
+      integer(c_size_t), value :: count
+      integer(c_int), value :: peer
+      integer(c_int) :: rc
+    end function
+    function ndsmk_dist_recv(p, count, peer) bind(c, name="ndsmk_dist_recv") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: p
+      integer(c_size_t), value :: count
+      integer(c_int), value :: peer
+      integer(c_int) :: rc
+    end function
+    function ndsmk_dist_allreduce_max_sum(ms) bind(c, name="ndsmk_dist_allreduce_max_sum") result(rc)
+      import :: c_double, c_int
+      real(c_double), intent(inout) :: ms(2)
+      integer(c_int) :: rc
+    end function
+  end interface
+
+  integer(c_size_t), parameter :: R8 = 8_c_size_t
+
+  type :: mg_world
+    integer :: nranks = 1
+    integer :: nlocal = 0            ! slabs held by this process
+    integer :: first = 0             ! global rank of loc(1)
+    logical :: rccl = .false.
+    type(mg_solver), allocatable :: loc(:)
+    type(slab_t), allocatable :: plan(:)     ! (0:nranks-1), identical on every rank
+    logical :: ghosts_ok = .false.   ! ghost planes of u(1) match the neighbours' owned planes
+    integer(ik) :: nzg = 0
+  end type
+
+contains
+
+  ! hierarchy + tables on the host only: the plan every rank derives (CPU tests)
+  function world_plan_only(nshape, qx, qy, qz, ngrids_req, nranks, plan) result(rc)
+    integer(c_int32_t), intent(in) :: nshape(3)
+    real(wp), intent(in) :: qx(:), qy(:), qz(:)
+    integer, intent(in) :: ngrids_req, nranks
+    type(slab_t), allocatable, intent(out) :: plan(:)
+    integer(c_int) :: rc
+    type(level_t), allocatable :: lev(:)
+    type(axis_xfer_t) :: tz
+    integer :: ng
+    logical :: ok
+    rc = NDSMK_EARG
+    ng = ndsm_level_count(3, nshape)
+    if (ngrids_req > 0) ng = min(ng, ngrids_req)
+    if (ng < 2) return
+    call build_levels(3, nshape, qx, qy, qz, ng, lev)
+    call build_axis_xfer(lev(1)%ax(3)%q, int(lev(1)%n(3)), lev(2)%ax(3)%q, int(lev(2)%n(3)), tz, ok)
+    if (.not. ok) return
+    call plan_slabs(int(lev(1)%n(3)), int(lev(2)%n(3)), tz, nranks, plan, ok)
+    if (ok) rc = 0
+  end function
+
+  ! rank < 0: loop-back world holding all nranks slabs in this process
+  function world_create(w, nshape, qx, qy, qz, bcs, ngrids_req, nranks, rank) result(rc)
+    type(mg_world), intent(out) :: w
+    integer(c_int32_t), intent(in) :: nshape(3)
+    real(wp), intent(in) :: qx(:), qy(:), qz(:)
+    character(len=1), intent(in) :: bcs(:)
+    integer, intent(in) :: ngrids_req, nranks, rank
+    integer(c_int) :: rc
+    integer :: i
+
+    rc = world_plan_only(nshape, qx, qy, qz, ngrids_req, nranks, w%plan)
+    if (rc /= 0) return
+    w%nranks = nranks
+    w%nzg = nshape(3)
+    if (rank < 0) then
+      w%rccl = .false.; w%first = 0; w%nlocal = nranks
+    else
+      rc = NDSMK_EARG
+      if (rank >= nranks) return
+      if (nranks > 1 .and. (ndsmk_dist_size() /= nranks .or. ndsmk_dist_rank() /= rank)) return
+      w%rccl = (nranks > 1); w%first = rank; w%nlocal = 1
+    end if
+    allocate (w%loc(w%nlocal))
+    do i = 1, w%nlocal
+      rc = mg_create(w%loc(i), 3, nshape, qx, qy, qz, bcs, ngrids_req, w%plan(w%first + i - 1))
+      if (rc /= 0) return
+    end do
+    w%ghosts_ok = .false.
+    rc = 0
+  end function
+
+  subroutine world_destroy(w)
+    type(mg_world), intent(inout) :: w
+    integer :: i
+    if (allocated(w%loc)) then
+      do i = 1, size(w%loc)
+        call mg_destroy(w%loc(i))
+      end do
+      deallocate (w%loc)
+    end if
+    if (allocated(w%plan)) deallocate (w%plan)
+    w%nlocal = 0
+  end subroutine
+
+  ! ------------------------------------------------------------------
+  ! host <-> slab.  The host pointer addresses global plane `gz0` of a (nx,ny,*)
+  ! array; planes [gz0, gz0+np) are copied where they intersect the slab's window
+  ! (ghosts included on upload, owned planes only on download).
+  ! ------------------------------------------------------------------
+  function world_upload(w, ilocal, which, host, gz0, np) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: ilocal, which, gz0, np
+    type(c_ptr), intent(in) :: host
+    integer(c_int) :: rc
+    integer :: a, b
+    integer(ik) :: cnt
+    type(c_ptr) :: dev
+    rc = NDSMK_EARG
+    if (ilocal < 1 .or. ilocal > w%nlocal) return
+    associate (s => w%loc(ilocal))
+      a = max(gz0, s%sl%k0, 0)
+      b = min(gz0 + np, s%sl%k0 + s%sl%nloc, int(w%nzg))
+      rc = 0
+      if (b <= a) return
+      dev = mg_level_ptr(s, 1, which, cnt)
+      rc = ndsmk_h2d(dptr_offset(dev, int(a - s%sl%k0, c_size_t) * int(s%plane1, c_size_t) * R8), &
+                     dptr_offset(host, int(a - gz0, c_size_t) * int(s%plane1, c_size_t) * R8), &
+                     int(b - a, c_size_t) * int(s%plane1, c_size_t) * R8)
+    end associate
+    if (which == MG_BUF_U) w%ghosts_ok = .false.
+  end function
+
+  ! host receives the slab's OWNED planes [z0, z1), packed from `host` on
+  function world_download(w, ilocal, which, host) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: ilocal, which
+    type(c_ptr), intent(in) :: host
+    integer(c_int) :: rc
+    integer(ik) :: cnt
+    type(c_ptr) :: dev
+    rc = NDSMK_EARG
+    if (ilocal < 1 .or. ilocal > w%nlocal) return
+    associate (s => w%loc(ilocal))
+      dev = mg_level_ptr(s, 1, which, cnt)
+      rc = ndsmk_d2h(host, dptr_offset(dev, int(s%sl%g, c_size_t) * int(s%plane1, c_size_t) * R8), &
+                     int(s%sl%z1 - s%sl%z0, c_size_t) * int(s%plane1, c_size_t) * R8)
+    end associate
+  end function
+
+  ! ------------------------------------------------------------------
+  ! ghost exchange of a level-1 sized array: `depth` planes per neighbour.
+  ! which: MG_BUF_U or MG_BUF_R
+  ! ------------------------------------------------------------------
+  function exchange(w, which, depth) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: which, depth
+    integer(c_int) :: rc
+    integer :: i, r, g, nown
+    integer(ik) :: cnt
+    integer(c_size_t) :: pl, nb
+    type(c_ptr) :: me, nbr
+
+    rc = 0
+    if (w%nranks == 1) return
+    if (w%rccl) then
+      rc = ndsmk_dist_group_start(); if (rc /= 0) return
+    end if
+    do i = 1, w%nlocal
+      associate (s => w%loc(i))
+        r = s%sl%rank; g = s%sl%g; nown = s%sl%z1 - s%sl%z0
+        pl = int(s%plane1, c_size_t)
+        nb = int(depth, c_size_t) * pl
+        me = mg_level_ptr(s, 1, which, cnt)
+        if (r < w%nranks - 1) then      ! upper neighbour r+1: my last owned planes -> its lower ghosts
+          if (w%rccl) then
+            rc = ndsmk_dist_send(dptr_offset(me, int(g + nown - depth, c_size_t) * pl * R8), nb, int(r + 1, c_int))
+            if (rc /= 0) return
+            rc = ndsmk_dist_recv(dptr_offset(me, int(g + nown, c_size_t) * pl * R8), nb, int(r + 1, c_int))
+            if (rc /= 0) return
+          else
+            nbr = mg_level_ptr(w%loc(i + 1), 1, which, cnt)
+            rc = ndsmk_d2d(dptr_offset(nbr, int(w%loc(i + 1)%sl%g - depth, c_size_t) * pl * R8), &
+                           dptr_offset(me, int(g + nown - depth, c_size_t) * pl * R8), nb * R8)
+            if (rc /= 0) return
+            rc = ndsmk_d2d(dptr_offset(me, int(g + nown, c_size_t) * pl * R8), &
+                           dptr_offset(nbr, int(w%loc(i + 1)%sl%g, c_size_t) * pl * R8), nb * R8)
+            if (rc /= 0) return
+          end if
+        end if
+        if (r > 0 .and. w%rccl) then    ! lower neighbour r-1 (loop-back: done from its side)
+          rc = ndsmk_dist_send(dptr_offset(me, int(g, c_size_t) * pl * R8), nb, int(r - 1, c_int))
+          if (rc /= 0) return
+          rc = ndsmk_dist_recv(dptr_offset(me, int(g - depth, c_size_t) * pl * R8), nb, int(r - 1, c_int))
+          if (rc /= 0) return
+        end if
+      end associate
+    end do
+    if (w%rccl) rc = ndsmk_dist_group_end()
+  end function
+
+  ! coarse planes computed by every rank -> rhs(2) on rank 0 ; u(2) = 0 there
+  function gather_coarse(w) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer(c_int) :: rc
+    integer :: i, r
+    integer(c_size_t) :: pl2
+    integer(ik) :: cnt
+    type(c_ptr) :: dst
+
+    rc = 0
+    if (w%rccl) then
+      rc = ndsmk_dist_group_start(); if (rc /= 0) return
+    end if
+    do i = 1, w%nlocal
+      associate (s => w%loc(i))
+        pl2 = int(s%plane2, c_size_t)
+        if (s%sl%rank == 0) then
+          dst = mg_level_ptr(s, 2, MG_BUF_RHS, cnt)
+          do r = 0, w%nranks - 1
+            if (w%plan(r)%ck1 <= w%plan(r)%ck0) cycle
+            if (r == 0) then
+              rc = ndsmk_d2d(dptr_offset(dst, int(w%plan(r)%ck0, c_size_t) * pl2 * R8), &
+                             dptr_offset(s%cbuf, int(w%plan(r)%ck0 - s%sl%cb0, c_size_t) * pl2 * R8), &
+                             int(w%plan(r)%ck1 - w%plan(r)%ck0, c_size_t) * pl2 * R8)
+            else if (w%rccl) then
+              rc = ndsmk_dist_recv(dptr_offset(dst, int(w%plan(r)%ck0, c_size_t) * pl2 * R8), &
+                                   int(w%plan(r)%ck1 - w%plan(r)%ck0, c_size_t) * pl2, int(r, c_int))
+            else
+              rc = ndsmk_d2d(dptr_offset(dst, int(w%plan(r)%ck0, c_size_t) * pl2 * R8), &
+                             dptr_offset(w%loc(r + 1)%cbuf, int(w%plan(r)%ck0 - w%plan(r)%cb0, c_size_t) * pl2 * R8), &
+                             int(w%plan(r)%ck1 - w%plan(r)%ck0, c_size_t) * pl2 * R8)
+            end if
+            if (rc /= 0) return
+          end do
+        else if (w%rccl .and. s%sl%ck1 > s%sl%ck0) then
+          rc = ndsmk_dist_send(dptr_offset(s%cbuf, int(s%sl%ck0 - s%sl%cb0, c_size_t) * pl2 * R8), &
+                               int(s%sl%ck1 - s%sl%ck0, c_size_t) * pl2, 0_c_int)
+          if (rc /= 0) return
+        end if
+      end associate
+    end do
+    if (w%rccl) then
+      rc = ndsmk_dist_group_end(); if (rc /= 0) return
+    end if
+    do i = 1, w%nlocal
+      if (w%loc(i)%sl%rank == 0) then
+        dst = mg_level_ptr(w%loc(i), 2, MG_BUF_U, cnt)
+        rc = ndsmk_fill0(dst, int(cnt, c_size_t) * R8)      ! ndsm_multigrid_core.f90:557-558
+      end if
+    end do
+  end function
+
+  ! u(2) planes [pk0, pk1) of rank 0 -> every rank's cbuf
+  function scatter_coarse(w) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer(c_int) :: rc
+    integer :: i, r
+    integer(c_size_t) :: pl2
+    integer(ik) :: cnt
+    type(c_ptr) :: src
+
+    rc = 0
+    if (w%rccl) then
+      rc = ndsmk_dist_group_start(); if (rc /= 0) return
+    end if
+    do i = 1, w%nlocal
+      associate (s => w%loc(i))
+        pl2 = int(s%plane2, c_size_t)
+        if (s%sl%rank == 0) then
+          src = mg_level_ptr(s, 2, MG_BUF_U, cnt)
+          do r = 0, w%nranks - 1
+            if (r == 0) then
+              rc = ndsmk_d2d(dptr_offset(s%cbuf, int(w%plan(r)%pk0 - s%sl%cb0, c_size_t) * pl2 * R8), &
+                             dptr_offset(src, int(w%plan(r)%pk0, c_size_t) * pl2 * R8), &
+                             int(w%plan(r)%pk1 - w%plan(r)%pk0, c_size_t) * pl2 * R8)
+            else if (w%rccl) then
+              rc = ndsmk_dist_send(dptr_offset(src, int(w%plan(r)%pk0, c_size_t) * pl2 * R8), &
+                                   int(w%plan(r)%pk1 - w%plan(r)%pk0, c_size_t) * pl2, int(r, c_int))
+            else
+              rc = ndsmk_d2d(dptr_offset(w%loc(r + 1)%cbuf, int(w%plan(r)%pk0 - w%plan(r)%cb0, c_size_t) * pl2 * R8), &
+                             dptr_offset(src, int(w%plan(r)%pk0, c_size_t) * pl2 * R8), &
+                             int(w%plan(r)%pk1 - w%plan(r)%pk0, c_size_t) * pl2 * R8)
+            end if
+            if (rc /= 0) return
+          end do
+        else if (w%rccl) then
+          rc = ndsmk_dist_recv(dptr_offset(s%cbuf, int(s%sl%pk0 - s%sl%cb0, c_size_t) * pl2 * R8), &
+                               int(s%sl%pk1 - s%sl%pk0, c_size_t) * pl2, 0_c_int)
+          if (rc /= 0) return
+        end if
+      end associate
+    end do
+    if (w%rccl) rc = ndsmk_dist_group_end()
+  end function
+
+  ! nsweeps x { make the ghosts current ; one fused sweep of every local slab }
+  function world_relax(w, nsweeps) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: nsweeps
+    integer(c_int) :: rc
+    integer :: sw, i
+    rc = 0
+    do sw = 1, nsweeps
+      if (.not. w%ghosts_ok) then
+        rc = exchange(w, MG_BUF_U, 2); if (rc /= 0) return
+        w%ghosts_ok = .true.
+      end if
+      do i = 1, w%nlocal
+        rc = mg_op(w%loc(i), MG_OP_RELAX_FUSED, 1, 1); if (rc /= 0) return
+      end do
+      w%ghosts_ok = .false.
+    end do
+  end function
+
+  function world_vcycle(w) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer(c_int) :: rc
+    integer :: i
+
+    ! ---- level 1, downwards (fine_to_coarse, ndsm_multigrid_core.f90:482-560)
+    rc = world_relax(w, w%loc(1)%ms); if (rc /= 0) return
+    if (.not. w%ghosts_ok) then         ! the residual reads one ghost plane of u
+      rc = exchange(w, MG_BUF_U, 2); if (rc /= 0) return
+      w%ghosts_ok = .true.
+    end if
+    do i = 1, w%nlocal
+      rc = mg_op(w%loc(i), MG_OP_RESIDUAL, 1, 1); if (rc /= 0) return
+    end do
+    rc = exchange(w, MG_BUF_R, w%plan(0)%g); if (rc /= 0) return
+    do i = 1, w%nlocal
+      rc = mg_slab_restrict(w%loc(i)); if (rc /= 0) return
+    end do
+    rc = gather_coarse(w); if (rc /= 0) return
+
+    ! ---- levels >= 2 on rank 0 ------------------------------------------
+    do i = 1, w%nlocal
+      if (w%loc(i)%sl%rank /= 0) cycle
+      if (w%loc(i)%ngrids == 2) then
+        rc = mg_op(w%loc(i), MG_OP_EXACT, 2, 1); if (rc /= 0) return
+      else
+        rc = mg_vcycle_from(w%loc(i), 2); if (rc /= 0) return
+      end if
+      rc = mg_op(w%loc(i), MG_OP_RELAX, 2, w%loc(i)%ms); if (rc /= 0) return   ! :642-644
+    end do
+
+    ! ---- level 1, upwards (coarse_to_fine, :593-684) --------------------
+    rc = scatter_coarse(w); if (rc /= 0) return
+    do i = 1, w%nlocal
+      rc = mg_slab_prolong(w%loc(i)); if (rc /= 0) return
+    end do
+    w%ghosts_ok = .false.
+    rc = world_relax(w, w%loc(1)%ms)
+  end function
+
+  ! V-cycles to tolerance; every rank returns the same du history
+  function world_solve(w, vc_tol, nmax, du_last, ncycles, ierr, hist) result(rc)
+    type(mg_world), intent(inout) :: w
+    real(wp), intent(in) :: vc_tol
+    integer, intent(in) :: nmax
+    real(wp), intent(out) :: du_last
+    integer, intent(out) :: ncycles, ierr
+    real(wp), intent(inout), optional :: hist(:)
+    integer(c_int) :: rc
+    real(wp) :: met(2), tot(2), du
+    integer :: it, i
+    integer(c_size_t) :: off, nb
+    integer(ik) :: nown
+
+    du = huge(du); ncycles = 0; ierr = 1
+    do i = 1, w%nlocal
+      rc = ndsmk_d2d(w%loc(i)%prev, w%loc(i)%dl(1)%u, int(w%loc(i)%npts1, c_size_t) * R8); if (rc /= 0) return
+    end do
+    do it = 1, nmax
+      rc = world_vcycle(w); if (rc /= 0) return
+      tot = 0
+      do i = 1, w%nlocal
+        associate (s => w%loc(i))
+          off = int(s%sl%g, c_size_t) * int(s%plane1, c_size_t) * R8
+          nown = int(s%sl%z1 - s%sl%z0, ik) * s%plane1
+          nb = int(nown, c_size_t)
+          rc = ndsmk_diff_metrics(dptr_offset(s%dl(1)%u, off), dptr_offset(s%prev, off), nown, 1_c_int, met)
+          if (rc /= 0) return
+          tot(1) = max(tot(1), met(1)); tot(2) = tot(2) + met(2)
+        end associate
+      end do
+      if (w%rccl) then
+        rc = ndsmk_dist_allreduce_max_sum(tot); if (rc /= 0) return
+      end if
+      if (w%loc(1)%use_max) then
+        du = tot(1)
+      else
+        du = tot(2) / (real(w%nzg, wp) * real(w%loc(1)%plane1, wp))
+      end if
+      ncycles = it
+      if (present(hist)) then
+        if (it <= size(hist)) hist(it) = du
+      end if
+      if (du < vc_tol) then
+        ierr = 0
+        exit
+      end if
+    end do
+    du_last = du
+    rc = 0
+  end function
+
+end module ndsmh_world

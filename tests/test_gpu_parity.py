@@ -288,3 +288,42 @@ def test_roundtrip_properties_large(hip):
     assert ierr == 0 and du < 1e-10 and ncyc <= 20
     assert np.abs(u - us).max() < 5e-5          # O(h^2) truncation error at h = 1/255
     assert all(hist[i + 1] < 0.5 * hist[i] for i in range(len(hist) - 1))
+
+
+@pytest.mark.parametrize("ns,nranks", (([64, 64, 64], 2), ([64, 48, 96], 3), ([128, 128, 128], 4), ([128, 64, 160], 8)),
+                         ids=lambda v: str(v))
+def test_slab_world_bitwise(hip, ns, nranks):
+    """z-slab decomposition (loop-back transport: all slabs on this GPU, neighbours reached by
+    device copies; production swaps those copies for RCCL send/recv): sweeps, a V-cycle and a whole
+    solve must return the SAME BITS as the single-domain solver."""
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
+    for bcs in BCS3:
+        S = hip.MGSolver(ns, mesh, bcs)
+        W = hip.World(ns, mesh, bcs, nranks)
+        assert W.nlocal == nranks and W.slabs[0]["z0"] == 0 and W.slabs[-1]["z1"] == ns[2]
+        S.upload(1, hip.BUF_U, u)
+        S.upload(1, hip.BUF_RHS, rhs)
+        W.upload(hip.BUF_U, u)
+        W.upload(hip.BUF_RHS, rhs)
+        S.op(hip.OP_RELAX, 1, 3)
+        W.relax(3)
+        assert np.array_equal(W.download(hip.BUF_U), S.download(1, hip.BUF_U)), f"sweeps {bcs}"
+        S.upload(1, hip.BUF_U, u)
+        W.upload(hip.BUF_U, u)
+        S.vcycle(2)
+        W.vcycle(2)
+        assert np.array_equal(W.download(hip.BUF_U), S.download(1, hip.BUF_U)), f"vcycle {bcs}"
+        S.close()
+        W.close()
+    bcs = "NDDNDD"
+    us, rhs = manufactured_poisson(mesh, bcs)
+    ierr, uref, du, hist, nc = hip.poisson_solve(np.zeros_like(us), rhs, mesh, bcs, hist_len=64)
+    W = hip.World(ns, mesh, bcs, nranks)
+    W.upload(hip.BUF_U, np.zeros_like(us))
+    W.upload(hip.BUF_RHS, rhs)
+    ierr2, du2, nc2, hist2 = W.solve(hist_len=64)
+    assert (ierr2, nc2, du2) == (ierr, nc, du) and list(hist2) == list(hist)
+    assert np.array_equal(W.download(hip.BUF_U), uref)
+    W.close()
