@@ -14,7 +14,8 @@
 #include "common.hpp"
 
 namespace ndsm {
-int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, bool *handled);
+int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
+                       bool force, int *sweeps_done);
 int launch_mean_shift(double *u, int64_t n);
 }
 
@@ -95,9 +96,13 @@ extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, double *ualt, const 
     if (g.ndim == 3) {
       bool done = false;
       if (variant != 1) {
-        int rc = ndsm::launch_rbgs3_fused(g, u, ualt, rhs, &done);
+        // all-Neumann levels shift the mean after EVERY sweep: one sweep per pass there
+        int ndone = 0;
+        int rc = ndsm::launch_rbgs3_fused(g, u, ualt, rhs, g.all_neumann ? 1 : nsweeps - sw, variant == 2, &ndone);
         if (rc) return rc;
-        if (done) {  // the sweep landed in the other array
+        done = ndone > 0;
+        if (done) {  // the sweeps landed in the other array
+          sw += ndone - 1;
           double *t = u;
           u = ualt;
           ualt = t;

@@ -60,7 +60,7 @@ __device__ __forceinline__ void st2(double *p, const d2 &a) {
 }
 // by value: selects on values, never on addresses
 __device__ __forceinline__ double pick(const d2 a, int e) { return e ? a.y : a.x; }
-__device__ __forceinline__ d2 put(const d2 a, int e, double v) {
+[[maybe_unused]] __device__ __forceinline__ d2 put(const d2 a, int e, double v) {
   d2 r;
   r.x = e ? a.x : v;
   r.y = e ? v : a.y;
@@ -69,7 +69,7 @@ __device__ __forceinline__ d2 put(const d2 a, int e, double v) {
 
 // geometry of slot s of this thread, recomputed where needed (cheap integer
 // ops) instead of being held in registers across the z loop
-template <int TXH, int TYH, int NT>
+template <int TXH, int TYH, int NT, int HALO>
 struct Slot {
   int li, lj, i, j, lo;
   bool live, in, own;
@@ -82,21 +82,43 @@ struct Slot {
     j = y0 + lj;
     live = p < NPX * TYH;
     in = live && i >= 0 && i + 1 < nx && j >= 0 && j < ny;
-    own = in && li >= 2 && li < TXH - 2 && lj >= 2 && lj < TYH - 2;
+    own = in && li >= HALO && li < TXH - HALO && lj >= HALO && lj < TYH - HALO;
     lo = live ? li + TXH * lj : 0;
   }
 };
 
-template <int TXH, int TYH, int NT, int WPS, bool RHS0>
+// S full sweeps (2S colour stages) in ONE pass over the data - temporal blocking.
+//
+// Stage t (t = 0 .. 2S-1; even = red, odd = black) of iteration k updates plane
+// k - t, so the 2S stages form a software pipeline skewed along z: a plane is
+// loaded once, visited by the 2S stages in 2S consecutive iterations while it
+// sits in LDS, and stored once.  HBM traffic per sweep therefore drops to ~1/S
+// of the single-sweep kernel's (plus halo: the loaded tile carries a ring of 2S
+// points, ring r being valid up to stage r-1, and a chunk warms up over 2S planes).
+//
+// Dependencies inside one iteration need NO barrier between stages:
+//   * stage t reads, in plane k-t, only points of the OTHER colour - last written
+//     by stage t-1 one iteration (= one barrier) ago;
+//   * its z+1 neighbour (plane k-t+1, same x,y => same thread) is what stage t-1
+//     produced a moment ago in this thread (register), its z-1 neighbour (plane
+//     k-t-1) is read from LDS before this thread's stage t+1 overwrites it;
+//   * every stage of an iteration updates the SAME element of the thread's
+//     x-pairs (colour and plane parity flip together), so no two stages of two
+//     threads ever touch the same LDS word.
+// Plane p lives in LDS buffer p mod 2S; the incoming plane k+1 replaces plane
+// k-2S+1, which the last stage has just finished and stored.
+template <int S, int TXH, int TYH, int NT, int WPS, bool RHS0>
 __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restrict__ u, double *__restrict__ uout,
                                                          const double *__restrict__ rhs, ndsmk_grid g,
                                                          FusedPlan pl) {
+  constexpr int NST = 2 * S;  // stages = LDS planes = halo width
   constexpr int NPX = TXH / 2;
   constexpr int NPAIR = NPX * TYH;
   constexpr int NS = (NPAIR + NT - 1) / NT;
-  constexpr int TXI = TXH - 4, TYI = TYH - 4;
+  constexpr int TXI = TXH - 2 * NST, TYI = TYH - 2 * NST;
   constexpr int PLANE = TXH * TYH;
-  using SlotT = Slot<TXH, TYH, NT>;
+  constexpr int BIG = 1 << 20;
+  using SlotT = Slot<TXH, TYH, NT, NST>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
   // ---- which (tile, chunk): consecutive y tiles share an XCD ---------
@@ -109,15 +131,17 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
   const int cz = t2 / pl.ntx;
 
   const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
-  const int x0 = tx * TXI - 2, y0 = ty * TYI - 2;
+  const int x0 = tx * TXI - NST, y0 = ty * TYI - NST;
   const int zs = g.zown0 + cz * pl.zc;
   const int ze = min(zs + pl.zc, g.zown1);
-  const int ks = max(zs - 2, 0);
-  const int ke = min(ze + 1, nz - 1);
+  const int ks = max(zs - NST, 0);
+  const int ke = min(ze - 1 + NST, nz - 1);  // last plane ever loaded
   const size_t sz = (size_t)nx * (size_t)ny;
   const int tid0 = (int)threadIdx.x;
   const int tid = tid0;
   const int fp = g.first_par & 1;
+  // tile edges that coincide with the physical boundary do not shrink the valid region
+  const bool openxl = x0 > 0, openxh = x0 + TXH < nx, openyl = y0 > 0, openyh = y0 + TYH < ny;
 
 #define NDSM_LOAD_PLANE(base, k, dst)                              \
   do {                                                              \
@@ -132,43 +156,50 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
     }                                                               \
   } while (0)
 
-  double *Pc = lds;          // plane k   : O_k, red points updated in place -> R_k
-  double *Pp = lds + PLANE;  // plane k-1 : R_{k-1}
-
-  // Register window.  Own values of planes k and k-1 are re-read from LDS; only
-  // what LDS does not hold stays in registers:
-  //   nxt  = O_{k+1} (arrived)            nn  = O_{k+2} (in flight)
-  //   m2e  = the one element of plane k-2 the black stage needs
-  //   rk   = rhs of plane k, rn = rhs of plane k+1 (in flight), rm1e = rhs element for the black stage
-  d2 nxt[NS], nn[NS], rk[NS], rn[NS];
-  double m2e[NS], rm1e[NS];
+  // Register window per slot (everything else is re-read from LDS):
+  //   nxt = plane k+1 (arrived), nn = plane k+2 (in flight)
+  //   mLe = the element of plane k-2S (final) the last stage needs as z-1 neighbour
+  //   rw[t] = rhs of plane k-t, rn = rhs of plane k+1 (in flight)
+  d2 nxt[NS], nn[NS];
+  d2 rw[RHS0 ? 1 : NS][RHS0 ? 1 : NST], rn[RHS0 ? 1 : NS];
+  double mLe[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     nxt[s].x = nxt[s].y = 0.0;
     nn[s].x = nn[s].y = 0.0;
-    rk[s].x = rk[s].y = 0.0;
-    rn[s].x = rn[s].y = 0.0;
-    m2e[s] = 0.0;
-    rm1e[s] = 0.0;
+    mLe[s] = 0.0;
+  }
+  if (!RHS0) {
+#pragma unroll
+    for (int s = 0; s < (RHS0 ? 1 : NS); ++s) {
+      rn[s].x = rn[s].y = 0.0;
+#pragma unroll
+      for (int t = 0; t < (RHS0 ? 1 : NST); ++t) rw[s][t].x = rw[s][t].y = 0.0;
+    }
   }
 
-  // ---- prologue: plane ks into LDS, plane ks+1 into registers ----------
+  // ---- prologue: plane ks into its LDS buffer, plane ks+1 into registers ----
   {
     d2 c0[NS];
     NDSM_LOAD_PLANE(u, ks, c0);
-    if (!RHS0) NDSM_LOAD_PLANE(rhs, ks, rk);
+    if (!RHS0) {
+      d2 r0[NS];
+      NDSM_LOAD_PLANE(rhs, ks, r0);
+#pragma unroll
+      for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rw[s][0] = r0[s];
+    }
     if (ks + 1 <= ke) NDSM_LOAD_PLANE(u, ks + 1, nxt);
+    double *B0 = lds + (ks % NST) * PLANE;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const SlotT q(tid, s, x0, y0, nx, ny);
-      if (q.live) st2(Pc + q.lo, c0[s]);
+      if (q.live) st2(B0 + q.lo, c0[s]);
     }
   }
   __syncthreads();
 
-  const int red_lo = max(zs - 1, 0), red_hi = min(ze, nz - 1);
-
-  for (int k = ks; k <= ze; ++k) {
+  const int klast = ze + NST - 2;  // iteration in which the last stage reaches plane ze-1
+  for (int k = ks; k <= klast; ++k) {
     const int kg = k + g.k0;
     // make the thread index opaque once per iteration: the slot geometry is then
     // recomputed (a few integer ops) instead of being kept live across the loop
@@ -178,80 +209,79 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
     if (k + 2 <= ke) NDSM_LOAD_PLANE(u, k + 2, nn);
     if (!RHS0 && k + 1 <= ke) NDSM_LOAD_PLANE(rhs, k + 1, rn);
 
-    const bool do_red = k >= red_lo && k <= red_hi && k >= g.lb[2] && k <= g.ub[2];
-    const int kb = k - 1;
-    const bool do_black = kb >= zs && kb < ze;
-    const int kbg = kb + g.k0;
-    const bool zupd = kb >= g.lb[2] && kb <= g.ub[2];
-
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const SlotT q(tid, s, x0, y0, nx, ny);
       if (!q.in) continue;
-      // the pair element that is red in plane k is the one that is black in plane k-1
+      // the element every stage of this iteration updates in this pair
       const int e = (((q.i + q.j + kg) & 1) == fp) ? 0 : 1;
-      const int ii = q.i + e;
+      const int ii = q.i + e, lii = q.li + e;
       const bool xmir = (e == 0) ? (ii == 0) : (ii == nx - 1);
       const int lxn = (e == 0) ? q.li - 1 : q.li + 2;
       const int ljl = (q.j == 0) ? q.lj + 1 : q.lj - 1;
       const int ljh = (q.j == ny - 1) ? q.lj - 1 : q.lj + 1;
       const bool inb = ii >= g.lb[0] && ii <= g.ub[0] && q.j >= g.lb[1] && q.j <= g.ub[1];
-      const d2 cc = ld2(Pc + q.lo);  // O_k
-      double cnew = pick(cc, e);
+      // distance to the nearest tile edge that is not the physical boundary:
+      // stage t may update a point only if that distance is > t
+      const int ring = min(min(openxl ? lii : BIG, openxh ? TXH - 1 - lii : BIG),
+                           min(openyl ? q.lj : BIG, openyh ? TYH - 1 - q.lj : BIG));
+      double zplus = pick(nxt[s], e);  // plane k+1, untouched by any stage yet
 
-      // ---------------- stage 0: red point of plane k -------------------
-      // ring 0 of the loaded region has no in-plane neighbours: never updated
-      if (do_red && inb && (xmir || (lxn >= 0 && lxn < TXH)) && ljl >= 0 && ljl < TYH && ljh >= 0 && ljh < TYH) {
-        const double other = pick(cc, 1 - e);
-        const double xn = xmir ? other : Pc[q.lj * TXH + lxn];
-        const double xs = (e == 0) ? (other + xn) : (xn + other);  // u(xh) + u(xl)
-        const double ys = Pc[ljh * TXH + q.li + e] + Pc[ljl * TXH + q.li + e];
-        const double m1v = Pp[q.lo + e];  // plane k-1, black there: still the old value
-        const double zhv = (kg == g.nzg - 1) ? m1v : pick(nxt[s], e);
-        const double zlv = (kg == 0) ? pick(nxt[s], e) : m1v;
-        const double zsum = zhv + zlv;
-        const double rr = RHS0 ? 0.0 : pick(rk[s], e);
-        const double unew = xs * g.w[0] + ys * g.w[1] + zsum * g.w[2] - rr;
-        cnew = g.w1 * unew;
-        Pc[q.lo + e] = cnew;
-      }
-
-      // ---------------- stage 1: black point of plane k-1 ---------------
-      if (do_black && q.own) {
-        d2 mm = ld2(Pp + q.lo);  // R_{k-1}
-        if (zupd && inb) {
-          const double other = pick(mm, 1 - e);
-          const double xn = xmir ? other : Pp[q.lj * TXH + lxn];
-          const double xs = (e == 0) ? (other + xn) : (xn + other);
-          const double ys = Pp[ljh * TXH + q.li + e] + Pp[ljl * TXH + q.li + e];
-          const double zhv = (kbg == g.nzg - 1) ? m2e[s] : cnew;
-          const double zlv = (kbg == 0) ? cnew : m2e[s];
+#pragma unroll
+      for (int t = 0; t < NST; ++t) {
+        const int p = k - t;  // plane of this stage
+        // stage t covers planes [zs-(NST-1-t), ze-1+(NST-1-t)] of the chunk
+        const bool act = p >= max(zs - (NST - 1 - t), 0) && p <= min(ze - 1 + (NST - 1 - t), nz - 1);
+        if (!act) continue;  // uniform; zplus is not needed by later stages either (their planes are inactive too or re-read)
+        double *buf = lds + ((p % NST) * PLANE);
+        double cur = buf[q.lo + e];
+        if (inb && p >= g.lb[2] && p <= g.ub[2] && ring > t) {
+          const int pg = p + g.k0;
+          const double other = buf[q.lo + 1 - e];
+          const double xn = xmir ? other : buf[q.lj * TXH + lxn];
+          const double xs = (e == 0) ? (other + xn) : (xn + other);  // u(xh) + u(xl)
+          const double ys = buf[ljh * TXH + lii] + buf[ljl * TXH + lii];
+          // plane p-1: its LDS copy, or (last stage) the saved final element
+          const double zminus = (t < NST - 1) ? lds[(((p - 1 + NST) % NST) * PLANE) + q.lo + e] : mLe[s];
+          const double zhv = (pg == g.nzg - 1) ? zminus : zplus;
+          const double zlv = (pg == 0) ? zplus : zminus;
           const double zsum = zhv + zlv;
-          const double rr = RHS0 ? 0.0 : rm1e[s];
+          const double rr = RHS0 ? 0.0 : pick(rw[RHS0 ? 0 : s][RHS0 ? 0 : t], e);
           const double unew = xs * g.w[0] + ys * g.w[1] + zsum * g.w[2] - rr;
-          mm = put(mm, e, g.w1 * unew);
+          cur = g.w1 * unew;
+          buf[q.lo + e] = cur;
         }
-        st2(uout + sz * (size_t)kb + (q.i + nx * q.j), mm);
+        zplus = cur;  // z+1 neighbour of the next stage's plane
       }
-      // what the NEXT iteration's black stage needs: plane k-1 at the element
-      // that is red there (final since the red stage of the previous iteration)
-      m2e[s] = Pp[q.lo + 1 - e];
-      rm1e[s] = RHS0 ? 0.0 : pick(rk[s], 1 - e);
+
+      // plane k-NST+1 has passed its last stage: store it, keep what the next
+      // iteration's last stage needs from it (its other element, already final)
+      const int pf = k - (NST - 1);
+      if (pf >= ks) {
+        const d2 fin = ld2(lds + ((pf % NST) * PLANE) + q.lo);
+        if (pf >= zs && pf < ze && q.own) st2(uout + sz * (size_t)pf + (q.i + nx * q.j), fin);
+        mLe[s] = pick(fin, 1 - e);
+      }
     }
 
-    __syncthreads();  // all reads of Pp (R_{k-1}) and all red writes into Pc are done
+    __syncthreads();  // every stage is done with its plane
 
-    // ---------------- rotate: O_{k+1} takes the place of R_{k-1} ---------
+    // ---- plane k+1 takes the LDS buffer of plane k-NST+1; shift the windows ----
     {
-      double *t = Pp;
-      Pp = Pc;
-      Pc = t;
+      double *bn = lds + (((k + 1) % NST) * PLANE);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const SlotT q(tid, s, x0, y0, nx, ny);
-        if (k + 1 <= ke && q.live) st2(Pc + q.lo, nxt[s]);
+        if (k + 1 <= ke && q.live) st2(bn + q.lo, nxt[s]);
         nxt[s] = nn[s];
-        if (!RHS0) rk[s] = rn[s];
+      }
+      if (!RHS0) {
+#pragma unroll
+        for (int s = 0; s < (RHS0 ? 1 : NS); ++s) {
+#pragma unroll
+          for (int t = (RHS0 ? 1 : NST) - 1; t > 0; --t) rw[s][t] = rw[s][t - 1];
+          rw[s][0] = rn[s];
+        }
       }
     }
     __syncthreads();
@@ -259,14 +289,16 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 #undef NDSM_LOAD_PLANE
 }
 
-template <int TXH, int TYH, int NT, int WPS>
+template <int S, int TXH, int TYH, int NT, int WPS>
 int launch_cfg(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int target_wgs) {
-  constexpr int TXI = TXH - 4, TYI = TYH - 4;
+  constexpr int NST = 2 * S;
+  constexpr int TXI = TXH - 2 * NST, TYI = TYH - 2 * NST;
+  static_assert(TXI > 0 && TYI > 0 && (TXH % 2) == 0, "tile");
   FusedPlan pl;
   pl.ntx = (g.n[0] + TXI - 1) / TXI;
   pl.nty = (g.n[1] + TYI - 1) / TYI;
   const int tiles = pl.ntx * pl.nty;
-  // z chunks: enough work items to fill the chip once, but chunks of >= 16 planes
+  // z chunks: enough work items to fill the chip, but chunks of >= 16 planes
   int nzc = (target_wgs + tiles - 1) / tiles;
   if (nzc < 1) nzc = 1;
   const int nzo = g.zown1 - g.zown0;  // owned planes
@@ -276,8 +308,8 @@ int launch_cfg(const ndsmk_grid &g, const double *u, double *uout, const double 
   pl.nzc = (nzo + zc - 1) / zc;
   pl.nwork = tiles * pl.nzc;
   const int nblk = ((pl.nwork + 7) / 8) * 8;
-  const size_t lds_bytes = sizeof(double) * 2 * TXH * TYH;
-  auto kfn = rbgs3_fused_k<TXH, TYH, NT, WPS, false>;
+  const size_t lds_bytes = sizeof(double) * NST * TXH * TYH;
+  auto kfn = rbgs3_fused_k<S, TXH, TYH, NT, WPS, false>;
   static bool attr_set = false;
   if (!attr_set) {
     NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -303,35 +335,50 @@ static int fused_cfg() {
   return cfg;
 }
 
-int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, bool *handled) {
-  *handled = false;
+int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
+                       bool force, int *sweeps_done) {
+  *sweeps_done = 0;
   if (!uout || g.ndim != 3 || (g.n[0] & 1) || g.n[0] < 16 || g.n[1] < 16 || g.zown1 - g.zown0 < 8) return 0;
   // a z-streaming workgroup walks >= 16 planes serially: with fewer than ~one
   // workgroup per CU the sweep is latency bound and the two colour passes win
   const int64_t npts = (int64_t)g.n[0] * g.n[1] * (g.zown1 - g.zown0);
-  if (npts < (int64_t)6 * 1024 * 1024 && g.zown1 - g.zown0 == g.n[2]) return 0;
+  const bool slab = g.zown1 - g.zown0 != g.n[2];
+  if (npts < (int64_t)6 * 1024 * 1024 && !slab && !force) return 0;
   // Tile choice measured on MI355X (scripts/tune_smoother.py): the sweep is bound
-  // by fabric traffic (halo rows + chunk warm-up planes, ~1.3x compulsory), and
-  // more, shorter chunks beat fewer, longer ones up to ~8 work items per CU.
+  // by fabric traffic (halo rows + chunk warm-up planes), and more, shorter chunks
+  // beat fewer, longer ones up to ~8 work items per CU.
   int rc;
   const int cfg = fused_cfg();
-  if (cfg == 0) {
+  const bool two = max_sweeps >= 2 && !slab && cfg != 99;  // slabs exchange 2 ghost planes per sweep
+  if (two) {
+    switch (cfg) {
+      case 21: rc = launch_cfg<2, 136, 30, 1024, 4>(g, u, uout, rhs, 512); break;
+      case 22: rc = launch_cfg<2, 136, 30, 1024, 4>(g, u, uout, rhs, 1024); break;
+      case 23: rc = launch_cfg<2, 136, 22, 768, 4>(g, u, uout, rhs, 768); break;
+      case 24: rc = launch_cfg<2, 72, 30, 512, 4>(g, u, uout, rhs, 1024); break;
+      default: rc = launch_cfg<2, 136, 30, 1024, 4>(g, u, uout, rhs, 768); break;
+    }
+    if (rc) return rc;
+    *sweeps_done = 2;
+    return 0;
+  }
+  if (cfg == 0 || cfg >= 20) {
     if (npts >= (int64_t)64 * 1024 * 1024)
-      rc = launch_cfg<132, 31, 512, 4>(g, u, uout, rhs, 2048);
+      rc = launch_cfg<1, 132, 31, 512, 4>(g, u, uout, rhs, 2048);
     else
-      rc = launch_cfg<68, 30, 256, 4>(g, u, uout, rhs, 1024);
+      rc = launch_cfg<1, 68, 30, 256, 4>(g, u, uout, rhs, 1024);
   } else {
     switch (cfg) {
-      case 1: rc = launch_cfg<132, 62, 1024, 4>(g, u, uout, rhs, 1024); break;
-      case 2: rc = launch_cfg<68, 30, 256, 4>(g, u, uout, rhs, 1024); break;
-      case 3: rc = launch_cfg<132, 31, 1024, 8>(g, u, uout, rhs, 2048); break;
-      case 4: rc = launch_cfg<68, 60, 512, 4>(g, u, uout, rhs, 1024); break;
-      case 5: rc = launch_cfg<132, 31, 512, 4>(g, u, uout, rhs, 1024); break;
-      default: rc = launch_cfg<132, 31, 512, 4>(g, u, uout, rhs, 2048); break;
+      case 1: rc = launch_cfg<1, 132, 62, 1024, 4>(g, u, uout, rhs, 1024); break;
+      case 2: rc = launch_cfg<1, 68, 30, 256, 4>(g, u, uout, rhs, 1024); break;
+      case 3: rc = launch_cfg<1, 132, 31, 1024, 8>(g, u, uout, rhs, 2048); break;
+      case 4: rc = launch_cfg<1, 68, 60, 512, 4>(g, u, uout, rhs, 1024); break;
+      case 5: rc = launch_cfg<1, 132, 31, 512, 4>(g, u, uout, rhs, 1024); break;
+      default: rc = launch_cfg<1, 132, 31, 512, 4>(g, u, uout, rhs, 2048); break;
     }
   }
   if (rc) return rc;
-  *handled = true;
+  *sweeps_done = 1;
   return 0;
 }
 

@@ -16,8 +16,9 @@ for ns in shapes:
     for bcs in ("NDDNDD", "DNDDND", "DDNDDN", "NNNNND", "DDDDDD"):
         S = _lib.MGSolver(ns, mesh, bcs)
         S.upload(1, _lib.BUF_RHS, rhs)
-        S.upload(1, _lib.BUF_U, u); S.op(_lib.OP_RELAX_COLOR, 1, 1); a = S.download(1, _lib.BUF_U)
-        S.upload(1, _lib.BUF_U, u); S.op(_lib.OP_RELAX_FUSED, 1, 1); b = S.download(1, _lib.BUF_U)
+        NSW = int(os.environ.get("NSW", "1"))
+        S.upload(1, _lib.BUF_U, u); S.op(_lib.OP_RELAX_COLOR, 1, NSW); a = S.download(1, _lib.BUF_U)
+        S.upload(1, _lib.BUF_U, u); S.op(_lib.OP_RELAX_FUSED, 1, NSW); b = S.download(1, _lib.BUF_U)
         S.close()
         d = np.argwhere(a != b)
         print(ns, bcs, "ndiff", len(d), "of", a.size, "max", np.abs(a - b).max() if len(d) else 0.0)
