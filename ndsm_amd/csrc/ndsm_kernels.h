@@ -68,6 +68,7 @@ typedef struct {
   int32_t f_beg, f_cnt;   /* local fine planes [f_beg, f_beg+f_cnt) are written by prolong_add */
   int32_t c_k0;           /* global index of plane 0 of the coarse array */
   int32_t c_beg, c_cnt;   /* local coarse planes [c_beg, c_beg+c_cnt) are written by restrict */
+  int32_t stream_ok;      /* host-checked: the LDS-streamed restriction (restrict_stream.hip) covers this pair */
 } ndsmk_xfer;
 
 /* ---- runtime ------------------------------------------------------- */
@@ -103,6 +104,14 @@ int ndsmk_relax(const ndsmk_grid *g, double *u, double *ualt, const double *rhs,
 int ndsmk_residual(const ndsmk_grid *g, const double *u, const double *rhs, double *r);
 /* rhs_c = R r_f ; also u_c = 0 if u_c != NULL (ndsm_multigrid_core.f90:551,557-558) */
 int ndsmk_restrict(const ndsmk_xfer *x, const double *r_f, double *rhs_c, double *u_c);
+/* footprint of the LDS-streamed restriction, for the host-side coverage check */
+void ndsmk_restrict_stream_tile(int *ci, int *cj, int *fx, int *fy, int *maxt);
+/* fused residual + restriction (resrest.hip): rhs_c = R (rhs - L u), u_c = 0, the
+ * residual never leaves the chip.  Only where ndsmk_resrest_tile's footprint
+ * covers every coarse tile's taps (checked by the host driver). */
+void ndsmk_resrest_tile(int *ci, int *cj, int *ux, int *uy, int *maxt);
+int ndsmk_residual_restrict(const ndsmk_grid *g, const ndsmk_xfer *x, const double *u, const double *rhs,
+                            double *rhs_c, double *u_c);
 /* u_f += P u_c (ndsm_multigrid_core.f90:659,672) */
 int ndsmk_prolong_add(const ndsmk_xfer *x, const double *u_c, double *u_f);
 /* blocking: out[0] = max|a-b|, out[1] = sum|a-b| ; then b <- a if copy != 0

@@ -17,6 +17,10 @@
 // Algorithmic traffic: restriction 9 B / fine point, prolong+correct 17 B / fine point.
 #include "common.hpp"
 
+namespace ndsm {
+int launch_restrict_stream(const ndsmk_xfer *x, const double *r_f, double *rhs_c, double *u_c);
+}
+
 namespace {
 
 struct XferDev {  // by-value kernel argument (pointers are device pointers)
@@ -113,6 +117,63 @@ __global__ __launch_bounds__(256) void prolong_add_k(const double *__restrict__ 
   uf[c] = uf[c] + v;
 }
 
+// Prolong + correct for the large 3-D levels: the 8 coarse values of a fine point
+// are shared with its neighbours, so a block stages the coarse footprint of its
+// fine tile (64 x 8 x 8 points -> at most 36 x 7 x 7 coarse values) in LDS once and
+// interpolates from there - the coarse level is read ~0.3x instead of 8x per fine
+// point, and what remains is the 16 B/pt read-modify-write of u.  Same arithmetic
+// and order as prolong_add_k.
+constexpr int PT_X = 64, PT_Y = 8, PT_Z = 8;
+constexpr int PC_X = 36, PC_Y = 7, PC_Z = 7;
+
+__global__ __launch_bounds__(256) void prolong_tile_k(const double *__restrict__ uc, double *__restrict__ uf,
+                                                      XferDev x) {
+  __shared__ double C[PC_Z][PC_Y][PC_X];
+  const int i0 = blockIdx.x * PT_X, j0 = blockIdx.y * PT_Y;
+  const int kl0 = x.f_beg + (int)blockIdx.z * PT_Z;               // local fine planes [kl0, kl1)
+  const int kl1 = min(kl0 + PT_Z, x.f_beg + x.f_cnt);
+  const int i1 = min(i0 + PT_X, x.nf[0]) - 1, j1 = min(j0 + PT_Y, x.nf[1]) - 1;
+  // coarse footprint (global coarse indices; z made local below)
+  const int cx0 = x.plo[0][i0], cy0 = x.plo[1][j0], cz0 = x.plo[2][kl0 + x.f_k0];
+  const int ncx = x.plo[0][i1] + 2 - cx0, ncy = x.plo[1][j1] + 2 - cy0;
+  const int ncz = x.plo[2][kl1 - 1 + x.f_k0] + 2 - cz0;
+  const size_t sy = (size_t)x.nc[0], sz = (size_t)x.nc[0] * (size_t)x.nc[1];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int p = tid; p < PC_X * PC_Y * PC_Z; p += 256) {
+    const int a = p % PC_X, b = (p / PC_X) % PC_Y, c = p / (PC_X * PC_Y);
+    if (a < ncx && b < ncy && c < ncz)
+      C[c][b][a] = uc[(size_t)(cx0 + a) + sy * (size_t)(cy0 + b) + sz * (size_t)(cz0 - x.c_k0 + c)];
+  }
+  __syncthreads();
+  const int i = i0 + threadIdx.x;
+  if (i > i1) return;
+  const int il = x.plo[0][i] - cx0;
+  const double wlx = x.pwl[0][i], whx = x.pwh[0][i];
+  for (int jj = threadIdx.y; jj < PT_Y; jj += 4) {
+    const int j = j0 + jj;
+    if (j > j1) break;
+    const int jl = x.plo[1][j] - cy0;
+    const double wly = x.pwl[1][j], why = x.pwh[1][j];
+    for (int kl = kl0; kl < kl1; ++kl) {
+      const int kg = kl + x.f_k0;
+      const int kc = x.plo[2][kg] - cz0;
+      const double wlz = x.pwl[2][kg], whz = x.pwh[2][kg];
+      double f0 = C[kc][jl][il], f1 = C[kc][jl][il + 1], f2 = C[kc][jl + 1][il], f3 = C[kc][jl + 1][il + 1];
+      double f4 = C[kc + 1][jl][il], f5 = C[kc + 1][jl][il + 1], f6 = C[kc + 1][jl + 1][il],
+             f7 = C[kc + 1][jl + 1][il + 1];
+      f0 = whz * f0 + wlz * f4;  // last dimension first (ndsm_interp.f90:128-154)
+      f1 = whz * f1 + wlz * f5;
+      f2 = whz * f2 + wlz * f6;
+      f3 = whz * f3 + wlz * f7;
+      f0 = why * f0 + wly * f2;
+      f1 = why * f1 + wly * f3;
+      const double v = whx * f0 + wlx * f1;
+      const size_t c = (size_t)i + (size_t)x.nf[0] * ((size_t)j + (size_t)x.nf[1] * (size_t)kl);
+      uf[c] = uf[c] + v;
+    }
+  }
+}
+
 int to_dev(const ndsmk_xfer *x, XferDev *d, int *ndim) {
   *ndim = (x->nf[2] == 1 && x->nc[2] == 1) ? 2 : 3;
   for (int a = 0; a < 3; ++a) {
@@ -152,6 +213,7 @@ extern "C" int ndsmk_restrict(const ndsmk_xfer *x, const double *r_f, double *rh
   XferDev d;
   int ndim;
   if (int rc = to_dev(x, &d, &ndim)) return rc;
+  if (ndim == 3 && x->stream_ok) return ndsm::launch_restrict_stream(x, r_f, rhs_c, u_c);
   dim3 block(32, 8, 1);
   dim3 grid((d.nc[0] + 31) / 32, (d.nc[1] + 7) / 8, d.c_cnt);
   if (ndim == 3)
@@ -169,6 +231,15 @@ extern "C" int ndsmk_prolong_add(const ndsmk_xfer *x, const double *u_c, double 
   if (int rc = to_dev(x, &d, &ndim)) return rc;
   dim3 block(64, 4, 1);
   dim3 grid((d.nf[0] + 63) / 64, (d.nf[1] + 3) / 4, d.f_cnt);
+  // the tiled kernel assumes a fine tile spans at most PC_* coarse points: true for every
+  // ratio (n_f-1)/(n_c-1) <= 2.2, i.e. all but the tiniest levels - which do not need it
+  if (ndim == 3 && (int64_t)d.nf[0] * d.nf[1] * d.f_cnt >= (int64_t)1 << 21 && d.nf[0] >= 64 && d.nc[0] >= 16 &&
+      d.nc[1] >= 16 && d.nc[2] >= 16) {
+    dim3 g2((d.nf[0] + PT_X - 1) / PT_X, (d.nf[1] + PT_Y - 1) / PT_Y, (d.f_cnt + PT_Z - 1) / PT_Z);
+    hipLaunchKernelGGL(prolong_tile_k, g2, block, 0, ndsm::stream(), u_c, u_f, d);
+    NDSM_LAUNCH_CHECK();
+    return 0;
+  }
   if (ndim == 3)
     hipLaunchKernelGGL(prolong_add_k<3>, grid, block, 0, ndsm::stream(), u_c, u_f, d);
   else

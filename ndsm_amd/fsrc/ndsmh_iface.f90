@@ -38,6 +38,7 @@ module ndsmh_iface
     real(c_double) :: w2(3) = 0
     integer(c_int32_t) :: f_k0 = 0, f_beg = 0, f_cnt = 1
     integer(c_int32_t) :: c_k0 = 0, c_beg = 0, c_cnt = 1
+    integer(c_int32_t) :: stream_ok = 0
   end type
 
   interface
@@ -135,6 +136,24 @@ module ndsmh_iface
       import :: ndsmk_xfer, c_ptr, c_int
       type(ndsmk_xfer), intent(in) :: x
       type(c_ptr), value :: r_f, rhs_c, u_c
+      integer(c_int) :: rc
+    end function
+
+    subroutine ndsmk_restrict_stream_tile(ci, cj, fx, fy, maxt) bind(c, name="ndsmk_restrict_stream_tile")
+      import :: c_int
+      integer(c_int), intent(out) :: ci, cj, fx, fy, maxt
+    end subroutine
+
+    subroutine ndsmk_resrest_tile(ci, cj, ux, uy, maxt) bind(c, name="ndsmk_resrest_tile")
+      import :: c_int
+      integer(c_int), intent(out) :: ci, cj, ux, uy, maxt
+    end subroutine
+
+    function ndsmk_residual_restrict(g, x, u, rhs, rhs_c, u_c) bind(c, name="ndsmk_residual_restrict") result(rc)
+      import :: ndsmk_grid, ndsmk_xfer, c_ptr, c_int
+      type(ndsmk_grid), intent(in) :: g
+      type(ndsmk_xfer), intent(in) :: x
+      type(c_ptr), value :: u, rhs, rhs_c, u_c
       integer(c_int) :: rc
     end function
 

@@ -29,11 +29,12 @@ module ndsmh_mg
   public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
   public :: MG_BUF_U, MG_BUF_RHS, MG_BUF_R
   public :: MG_OP_RELAX, MG_OP_RESIDUAL, MG_OP_RESTRICT, MG_OP_PROLONG, MG_OP_EXACT, MG_OP_RELAX_COLOR, &
-            MG_OP_RELAX_FUSED
+            MG_OP_RELAX_FUSED, MG_OP_RESREST
 
   integer, parameter :: MG_BUF_U = 0, MG_BUF_RHS = 1, MG_BUF_R = 2
   integer, parameter :: MG_OP_RELAX = 0, MG_OP_RESIDUAL = 1, MG_OP_RESTRICT = 2, MG_OP_PROLONG = 3, &
-                        MG_OP_EXACT = 4, MG_OP_RELAX_COLOR = 5, MG_OP_RELAX_FUSED = 6
+                        MG_OP_EXACT = 4, MG_OP_RELAX_COLOR = 5, MG_OP_RELAX_FUSED = 6, &
+                        MG_OP_RESREST = 7
 
   integer(c_size_t), parameter :: R8 = 8_c_size_t, I4 = 4_c_size_t
 
@@ -45,6 +46,7 @@ module ndsmh_mg
   type :: dev_xfer
     type(ndsmk_xfer) :: x
     type(c_ptr) :: blob = c_null_ptr
+    logical :: fused_rr = .false.   ! the fused residual+restriction kernel covers this level pair
   end type
 
   type :: mg_solver
@@ -62,6 +64,7 @@ module ndsmh_mg
     type(c_ptr) :: info = c_null_ptr     ! 2 x int64 on the device: exact sweeps, unconverged coarse solves
     integer(ik) :: vcycles_done = 0
     integer(ik) :: npts1 = 0             ! elements of the level-1 device arrays (local window if z-slab)
+    logical :: allow_fused_rr = .false.  ! resrest.hip is correct but not yet faster than residual + streamed restriction
     ! ---- z-slab mode (level 1 distributed, SURVEY 8e); unused otherwise
     logical :: slab = .false.
     logical :: has_coarse = .true.       ! levels >= 2 live here (rank 0 only when distributed)
@@ -189,6 +192,8 @@ contains
       o_rcnt(d) = total; total = total + pad8(int(t(d)%nc, c_size_t) * I4)
     end do
     rc = ndsmk_alloc(s%xf(l)%blob, total); if (rc /= 0) return
+    s%xf(l)%fused_rr = fused_rr_applies(s, l, t)
+    s%xf(l)%x%stream_ok = merge(1, 0, stream_restrict_applies(s, l, t))
 
     s%xf(l)%x%nf = s%lev(l)%n
     s%xf(l)%x%nc = s%lev(l + 1)%n
@@ -224,6 +229,68 @@ contains
       integer(c_size_t) :: p
       p = ((b + 7_c_size_t) / 8_c_size_t) * 8_c_size_t
     end function
+  end function
+
+  ! Does restrict_stream.hip cover the transfer l -> l+1?  Same idea as below,
+  ! with that kernel's footprint (no stencil halo).
+  function stream_restrict_applies(s, l, t) result(ok)
+    type(mg_solver), intent(in) :: s
+    integer, intent(in) :: l
+    type(axis_xfer_t), intent(in) :: t(3)
+    logical :: ok
+    integer(c_int) :: ci, cj, fx, fy, mt
+    integer :: a0, a1, f0, nt, k
+    ok = .false.
+    if (s%ndim /= 3) return
+    if (mod(s%lev(l)%n(1), 2) /= 0) return
+    if (s%lev(l)%npts < 6_ik * 1024_ik * 1024_ik) return
+    call ndsmk_restrict_stream_tile(ci, cj, fx, fy, mt)
+    if (any([t(1)%maxt, t(2)%maxt, t(3)%maxt] > mt)) return
+    nt = (t(1)%nc + ci - 1) / ci
+    do k = 0, nt - 1
+      a0 = k * ci + 1; a1 = min(a0 + ci - 1, int(t(1)%nc))
+      f0 = iand(t(1)%rlo(a0), not(1))
+      if (t(1)%rlo(a1) + t(1)%rcnt(a1) - 1 > f0 + fx - 1) return
+    end do
+    nt = (t(2)%nc + cj - 1) / cj
+    do k = 0, nt - 1
+      a0 = k * cj + 1; a1 = min(a0 + cj - 1, int(t(2)%nc))
+      f0 = t(2)%rlo(a0)
+      if (t(2)%rlo(a1) + t(2)%rcnt(a1) - 1 > f0 + fy - 1) return
+    end do
+    ok = .true.
+  end function
+
+  ! Does resrest.hip cover the transfer l -> l+1?  3-D, even nx, a level large
+  ! enough to fill the chip, at most `maxt` taps per dimension, and - the grids
+  ! being non-nested - the fine taps of every coarse tile inside the tile's
+  ! loaded footprint.
+  function fused_rr_applies(s, l, t) result(ok)
+    type(mg_solver), intent(in) :: s
+    integer, intent(in) :: l
+    type(axis_xfer_t), intent(in) :: t(3)
+    logical :: ok
+    integer(c_int) :: ci, cj, ux, uy, mt
+    integer :: a0, a1, f0, nt, k
+    ok = .false.
+    if (s%ndim /= 3) return
+    if (mod(s%lev(l)%n(1), 2) /= 0) return
+    if (s%lev(l)%npts < 6_ik * 1024_ik * 1024_ik) return
+    call ndsmk_resrest_tile(ci, cj, ux, uy, mt)
+    if (any([t(1)%maxt, t(2)%maxt, t(3)%maxt] > mt)) return
+    nt = (t(1)%nc + ci - 1) / ci
+    do k = 0, nt - 1
+      a0 = k * ci + 1; a1 = min(a0 + ci - 1, int(t(1)%nc))
+      f0 = iand(t(1)%rlo(a0) - 1, not(1))
+      if (t(1)%rlo(a1) + t(1)%rcnt(a1) - 1 > f0 + ux - 2) return
+    end do
+    nt = (t(2)%nc + cj - 1) / cj
+    do k = 0, nt - 1
+      a0 = k * cj + 1; a1 = min(a0 + cj - 1, int(t(2)%nc))
+      f0 = t(2)%rlo(a0) - 1
+      if (t(2)%rlo(a1) + t(2)%rcnt(a1) - 1 > f0 + uy - 2) return
+    end do
+    ok = .true.
   end function
 
   ! Re-target an existing hierarchy at another set of boundary letters: only the
@@ -376,6 +443,11 @@ contains
     case (MG_OP_RESTRICT)       ! r(level) -> rhs(level+1), u(level+1) = 0
       if (level >= s%ngrids) return
       rc = ndsmk_restrict(s%xf(level)%x, s%r, s%dl(level + 1)%rhs, s%dl(level + 1)%u)
+    case (MG_OP_RESREST)        ! fused residual + restrict (error if the level pair is not covered)
+      if (level >= s%ngrids) return
+      if (.not. s%xf(level)%fused_rr) return
+      rc = ndsmk_residual_restrict(s%lev(level)%g, s%xf(level)%x, s%dl(level)%u, s%dl(level)%rhs, &
+                                   s%dl(level + 1)%rhs, s%dl(level + 1)%u)
     case (MG_OP_PROLONG)        ! u(level) += P u(level+1)
       if (level >= s%ngrids) return
       rc = ndsmk_prolong_add(s%xf(level)%x, s%dl(level + 1)%u, s%dl(level)%u)
@@ -407,8 +479,13 @@ contains
     ! descend: pre-smooth, residual, restrict (fine_to_coarse, :482-560)
     do l = ltop, s%ngrids - 1
       rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
-      rc = mg_op(s, MG_OP_RESIDUAL, l, 1); if (rc /= 0) return
-      rc = mg_op(s, MG_OP_RESTRICT, l, 1); if (rc /= 0) return
+      if (s%xf(l)%fused_rr .and. .not. (s%slab .and. l == 1) .and. s%allow_fused_rr) then
+        rc = ndsmk_residual_restrict(s%lev(l)%g, s%xf(l)%x, s%dl(l)%u, s%dl(l)%rhs, s%dl(l + 1)%rhs, s%dl(l + 1)%u)
+        if (rc /= 0) return
+      else
+        rc = mg_op(s, MG_OP_RESIDUAL, l, 1); if (rc /= 0) return
+        rc = mg_op(s, MG_OP_RESTRICT, l, 1); if (rc /= 0) return
+      end if
     end do
 
     ! coarsest grid: iterate the smoother to ex_tol (solve_exact, :728-800)

@@ -107,6 +107,43 @@ def test_transfer3d_bitwise(hip, port, ns):
     S.close()
 
 
+@pytest.mark.parametrize("ns", ([128, 128, 128], [200, 100, 120], [256, 192, 160]), ids=_tag)
+def test_large_level_kernels_bitwise(hip, port, ns):
+    """the kernels that only serve large levels - temporally blocked fused smoother, LDS-streamed
+    restriction, LDS-tiled prolongation, fused residual+restriction - against the oracle, level 1 -> 2"""
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
+    bcs = "DNDDND"
+    S = hip.MGSolver(ns, mesh, bcs)
+    shapes, _ = port.hierarchy(ns, mesh)
+    c = rand_field(tuple(int(v) for v in shapes[1][::-1]), 4001)
+    S.upload(1, hip.BUF_U, u)
+    S.upload(1, hip.BUF_RHS, rhs)
+    S.op(hip.OP_RELAX_FUSED, 1, 5)                     # 2 + 2 + 1 sweeps
+    want = u
+    for _ in range(5):
+        want = port.relax3d(want, rhs, mesh, bcs)
+    assert np.array_equal(S.download(1, hip.BUF_U), want)
+    r = port.residual3d(want, rhs, mesh, bcs)
+    S.op(hip.OP_RESIDUAL, 1)
+    assert np.array_equal(S.download(1, hip.BUF_R), r)
+    S.op(hip.OP_RESTRICT, 1)
+    rc = port.restrict(r, ns, mesh, 1)
+    assert np.array_equal(S.download(2, hip.BUF_RHS), rc)
+    assert not S.download(2, hip.BUF_U).any()
+    S.upload(2, hip.BUF_RHS, np.zeros_like(rc))
+    try:
+        S.op(hip.OP_RESREST, 1)                        # fused variant, where the tile covers the taps
+        assert np.array_equal(S.download(2, hip.BUF_RHS), rc)
+    except hip.NdsmHipError:
+        pass
+    S.upload(2, hip.BUF_U, c)
+    S.op(hip.OP_PROLONG, 1)
+    assert np.array_equal(S.download(1, hip.BUF_U), want + port.interp(c, ns, mesh, 1))
+    S.close()
+
+
 @pytest.mark.parametrize("ns", KERNEL_SHAPES_3D, ids=_tag)
 def test_kernels3d_golden(hip, golden_dir, ns):
     """same kernels against the reference's own outputs (no oracle involved)"""
