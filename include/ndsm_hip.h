@@ -108,6 +108,8 @@ int ndsm_hip_mg_set_ms(void *handle, int ms);
 /* which: 0 = u, 1 = rhs, 2 = residual scratch (level-1 sized) */
 int ndsm_hip_mg_upload(void *handle, int level, int which, const double *host);
 int ndsm_hip_mg_download(void *handle, int level, int which, double *host);
+/* declare rhs(1) == 0 (Laplace problem, the vector-potential case): kernels skip reading it; same bits */
+int ndsm_hip_mg_zero_rhs(void *handle);
 /* op: 0 relax (count sweeps), 1 residual -> scratch, 2 restrict scratch(level) -> rhs(level+1)
  * and zero u(level+1), 3 u(level) += P u(level+1), 4 coarsest-grid solve, 5/6 relax forced to
  * the two-pass / fused kernel.  Asynchronous. */

@@ -49,6 +49,7 @@ def load_library(path=None):
     L.ndsm_hip_mg_set_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndsm_hip_mg_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
     L.ndsm_hip_mg_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
+    L.ndsm_hip_mg_zero_rhs.argtypes = [ctypes.c_void_p]
     L.ndsm_hip_mg_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.ndsm_hip_mg_vcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndsm_hip_mg_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, _dp, _ip, _dp, ctypes.c_int]
@@ -157,6 +158,10 @@ class MGSolver:
             return full.ravel()[:out.size].reshape(out.shape).copy()
         _check(self.L.ndsm_hip_mg_download(self.h, level, which, _d(out)), "download", self.L)
         return out
+
+    def zero_rhs(self):
+        """rhs(1) == 0: the Laplace case of the vector potential; kernels then skip the rhs read"""
+        _check(self.L.ndsm_hip_mg_zero_rhs(self.h), "zero_rhs", self.L)
 
     def op(self, op, level, count=1):
         _check(self.L.ndsm_hip_mg_op(self.h, op, level, count), f"op {op}", self.L)

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kThreads) void solve_exact_k(double *__restrict__ u
   const int n = nx * ny * nz;
   for (int p = threadIdx.x; p < n; p += kThreads) {
     u[p] = u_g[p];
-    rhs[p] = rhs_g[p];
+    rhs[p] = rhs_g ? rhs_g[p] : 0.0;
     sav[p] = 0.0;
   }
   __syncthreads();

@@ -94,6 +94,7 @@ int ndsmk_timer_stop(double *ms);           /* blocking; elapsed between start a
  * 3-D, ndsm_poisson.f90:451-549 in 2-D incl. the all-Neumann mean shift).
  * variant: 0 = pick the fastest valid kernel, 1 = two-pass colour kernels (in
  * place), 2 = fused z-streaming kernel (3-D only, out of place).
+ * rhs == NULL means rhs is identically zero (never dereferenced; same bits).
  * ualt: a second array of the level's size (may be NULL: colour kernels only).
  * The fused kernel ping-pongs u <-> ualt once per sweep; on return
  * *result_in_alt = 1 means the swept field is in ualt and the caller must swap

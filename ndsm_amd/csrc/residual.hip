@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void residual3(const double *__restrict__ u, c
   const double vh = u[j == ny - 1 ? c - sy : c + sy];
   const double wl = u[kg == 0 ? c + sz : c - sz];
   const double wh = u[kg == g.nzg - 1 ? c - sz : c + sz];
-  const double v = (ul + uh) * g.w[0] + (vl + vh) * g.w[1] + (wl + wh) * g.w[2] - rhs[c] - u[c] * g.wc;
+  const double v = (ul + uh) * g.w[0] + (vl + vh) * g.w[1] + (wl + wh) * g.w[2] - (rhs ? rhs[c] : 0.0) - u[c] * g.wc;
   r[c] = -v;
 }
 
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void residual2(const double *__restrict__ u, c
   double lap = 0.0;  // ndsm_poisson.f90:334-345
   lap = lap + (xl - 2 * uc + xh) * g.w[0];
   lap = lap + (yl - 2 * uc + yh) * g.w[1];
-  r[c] = rhs[c] - lap;
+  r[c] = (rhs ? rhs[c] : 0.0) - lap;
 }
 
 }  // namespace

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void rbgs3_color(double *__restrict__ u, const
   const double unew = (u[lin3(xh, j, k, nx, ny)] + u[lin3(xl, j, k, nx, ny)]) * g.w[0] +
                       (u[lin3(i, yh, k, nx, ny)] + u[lin3(i, yl, k, nx, ny)]) * g.w[1] +
                       (u[lin3(i, j, zh, nx, ny)] + u[lin3(i, j, zl, nx, ny)]) * g.w[2] -
-                      rhs[lin3(i, j, k, nx, ny)];
+                      (rhs ? rhs[lin3(i, j, k, nx, ny)] : 0.0);  // rhs == nullptr: identically zero
   u[lin3(i, j, k, nx, ny)] = g.w1 * unew;
 }
 
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void rbgs2_color(double *__restrict__ u, const
   double un = 0.0;  // ndsm_poisson.f90:603-617
   un = un + u[(size_t)xl + (size_t)nx * j] * g.w[0] + u[(size_t)xh + (size_t)nx * j] * g.w[0];
   un = un + u[(size_t)i + (size_t)nx * yl] * g.w[1] + u[(size_t)i + (size_t)nx * yh] * g.w[1];
-  u[(size_t)i + (size_t)nx * j] = (un - rhs[(size_t)i + (size_t)nx * j]) * g.w1;
+  u[(size_t)i + (size_t)nx * j] = (un - (rhs ? rhs[(size_t)i + (size_t)nx * j] : 0.0)) * g.w1;
 }
 
 }  // namespace

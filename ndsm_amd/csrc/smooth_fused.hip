@@ -309,14 +309,27 @@ int launch_cfg(const ndsmk_grid &g, const double *u, double *uout, const double 
   pl.nwork = tiles * pl.nzc;
   const int nblk = ((pl.nwork + 7) / 8) * 8;
   const size_t lds_bytes = sizeof(double) * NST * TXH * TYH;
-  auto kfn = rbgs3_fused_k<S, TXH, TYH, NT, WPS, false>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds_bytes));
-    attr_set = true;
+  // rhs == nullptr: the level's right-hand side is identically zero (level 1 of NDSM's
+  // Laplace problems, ndsm_vector_potential.f90:640-641): x - 0.0 == x exactly, so the
+  // variant that never loads rhs returns the same bits with 8 B/LUP less traffic
+  static bool attr_set[2] = {false, false};
+  if (rhs) {
+    auto kfn = rbgs3_fused_k<S, TXH, TYH, NT, WPS, false>;
+    if (!attr_set[0]) {
+      NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes));
+      attr_set[0] = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(NT), lds_bytes, ndsm::stream(), u, uout, rhs, g, pl);
+  } else {
+    auto kfn = rbgs3_fused_k<S, TXH, TYH, NT, WPS, true>;
+    if (!attr_set[1]) {
+      NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes));
+      attr_set[1] = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(NT), lds_bytes, ndsm::stream(), u, uout, rhs, g, pl);
   }
-  hipLaunchKernelGGL(kfn, dim3(nblk), dim3(NT), lds_bytes, ndsm::stream(), u, uout, rhs, g, pl);
   NDSM_LAUNCH_CHECK();
   return 0;
 }

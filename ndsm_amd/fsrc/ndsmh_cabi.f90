@@ -390,6 +390,17 @@ contains
     rc = NDSMK_EARG
     if (.not. c_associated(d)) return
     rc = ndsmk_h2d(d, host, int(n, c_size_t) * 8_c_size_t)
+    if (level == 1 .and. which == MG_BUF_RHS) call mg_mark_rhs_set(s)
+  end function
+
+  ! declare the level-1 right-hand side identically zero (Laplace problem): the
+  ! kernels then never read it; results are bit-identical
+  function ndsm_hip_mg_zero_rhs(handle) bind(c, name="ndsm_hip_mg_zero_rhs") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int) :: rc
+    type(mg_solver), pointer :: s
+    call c_f_pointer(handle, s)
+    rc = mg_zero_rhs(s)
   end function
 
   function ndsm_hip_mg_download(handle, level, which, host) bind(c, name="ndsm_hip_mg_download") result(rc)

@@ -26,6 +26,7 @@ module ndsmh_mg
 
   public :: mg_solver, mg_create, mg_destroy, mg_vcycle, mg_solve
   public :: mg_set_u, mg_set_rhs, mg_get_u, mg_zero_rhs, mg_level_ptr, mg_op, mg_read_info
+  public :: mg_mark_rhs_set
   public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
   public :: MG_BUF_U, MG_BUF_RHS, MG_BUF_R
   public :: MG_OP_RELAX, MG_OP_RESIDUAL, MG_OP_RESTRICT, MG_OP_PROLONG, MG_OP_EXACT, MG_OP_RELAX_COLOR, &
@@ -64,6 +65,7 @@ module ndsmh_mg
     type(c_ptr) :: info = c_null_ptr     ! 2 x int64 on the device: exact sweeps, unconverged coarse solves
     integer(ik) :: vcycles_done = 0
     integer(ik) :: npts1 = 0             ! elements of the level-1 device arrays (local window if z-slab)
+    logical :: rhs1_zero = .false.        ! level-1 rhs is identically zero: kernels skip reading it
     logical :: allow_fused_rr = .false.  ! resrest.hip is correct but not yet faster than residual + streamed restriction
     ! ---- z-slab mode (level 1 distributed, SURVEY 8e); unused otherwise
     logical :: slab = .false.
@@ -323,6 +325,11 @@ contains
     rc = ndsmk_d2d(d_dst, s%dl(1)%u, int(s%npts1, c_size_t) * R8)
   end function
 
+  subroutine mg_mark_rhs_set(s)
+    type(mg_solver), intent(inout) :: s
+    s%rhs1_zero = .false.
+  end subroutine
+
   function mg_reset_info(s) result(rc)
     type(mg_solver), intent(inout) :: s
     integer(c_int) :: rc
@@ -371,12 +378,14 @@ contains
     type(c_ptr), intent(in) :: h_rhs
     integer(c_int) :: rc
     rc = ndsmk_h2d(s%dl(1)%rhs, h_rhs, int(s%npts1, c_size_t) * R8)
+    s%rhs1_zero = .false.
   end function
 
   function mg_zero_rhs(s) result(rc)
     type(mg_solver), intent(inout) :: s
     integer(c_int) :: rc
     rc = ndsmk_fill0(s%dl(1)%rhs, int(s%npts1, c_size_t) * R8)
+    s%rhs1_zero = .true.       ! NDSM's 3-D problems are Laplace problems (ndsm_vector_potential.f90:640-641)
   end function
 
   function mg_get_u(s, h_u) result(rc)
@@ -414,6 +423,15 @@ contains
     sweeps = buf(1); unconverged = buf(2)
   end function
 
+  ! rhs pointer handed to the kernels: null when the level's rhs is known to be zero
+  function rhs_of(s, level) result(p)
+    type(mg_solver), intent(in) :: s
+    integer, intent(in) :: level
+    type(c_ptr) :: p
+    p = s%dl(level)%rhs
+    if (level == 1 .and. s%rhs1_zero) p = c_null_ptr
+  end function
+
   ! ------------------------------------------------------------------
   ! single grid operations (also the building blocks of the cycle)
   ! ------------------------------------------------------------------
@@ -431,7 +449,7 @@ contains
     select case (op)
     case (MG_OP_RELAX, MG_OP_RELAX_COLOR, MG_OP_RELAX_FUSED)
       variant = merge(0, merge(1, 2, op == MG_OP_RELAX_COLOR), op == MG_OP_RELAX)
-      rc = ndsmk_relax(s%lev(level)%g, s%dl(level)%u, s%dl(level)%ualt, s%dl(level)%rhs, int(count, c_int), &
+      rc = ndsmk_relax(s%lev(level)%g, s%dl(level)%u, s%dl(level)%ualt, rhs_of(s, level), int(count, c_int), &
                        int(variant, c_int), swapped)
       if (rc == 0 .and. swapped /= 0) then      ! the swept field lives in the partner array now
         tmp = s%dl(level)%u
@@ -439,7 +457,7 @@ contains
         s%dl(level)%ualt = tmp
       end if
     case (MG_OP_RESIDUAL)
-      rc = ndsmk_residual(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, s%r)
+      rc = ndsmk_residual(s%lev(level)%g, s%dl(level)%u, rhs_of(s, level), s%r)
     case (MG_OP_RESTRICT)       ! r(level) -> rhs(level+1), u(level+1) = 0
       if (level >= s%ngrids) return
       rc = ndsmk_restrict(s%xf(level)%x, s%r, s%dl(level + 1)%rhs, s%dl(level + 1)%u)

@@ -184,6 +184,7 @@ contains
                      int(b - a, c_size_t) * int(s%plane1, c_size_t) * R8)
     end associate
     if (which == MG_BUF_U) w%ghosts_ok = .false.
+    if (which == MG_BUF_RHS) call mg_mark_rhs_set(w%loc(ilocal))
   end function
 
   ! host receives the slab's OWNED planes [z0, z1), packed from `host` on

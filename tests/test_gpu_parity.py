@@ -141,6 +141,20 @@ def test_large_level_kernels_bitwise(hip, port, ns):
     S.upload(2, hip.BUF_U, c)
     S.op(hip.OP_PROLONG, 1)
     assert np.array_equal(S.download(1, hip.BUF_U), want + port.interp(c, ns, mesh, 1))
+    # Laplace fast path: rhs declared zero -> kernels never read it; same bits as rhs = 0 uploaded
+    zero = np.zeros(shp)
+    S.upload(1, hip.BUF_U, u)
+    S.zero_rhs()
+    S.op(hip.OP_RELAX_FUSED, 1, 5)
+    S.op(hip.OP_RESIDUAL, 1)
+    want0 = u
+    for _ in range(5):
+        want0 = port.relax3d(want0, zero, mesh, bcs)
+    assert np.array_equal(S.download(1, hip.BUF_U), want0)
+    assert np.array_equal(S.download(1, hip.BUF_R), port.residual3d(want0, zero, mesh, bcs))
+    S.upload(1, hip.BUF_U, u)
+    S.op(hip.OP_RELAX_COLOR, 1, 2)
+    assert np.array_equal(S.download(1, hip.BUF_U), port.relax3d(port.relax3d(u, zero, mesh, bcs), zero, mesh, bcs))
     S.close()
 
 
