@@ -318,7 +318,11 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / world / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "level-1 RB-GS sweep (red+black, fused)" + ("" if world == 1 else ", per GPU, halo exchange included"),
-                     "bytes_per_lup": BYTES_PER_LUP},
+                     "bytes_per_lup": BYTES_PER_LUP,
+                     "sweeps_per_launch": 2, "algorithmic_bytes_per_launch": 2 * BYTES_PER_LUP * npts / world,
+                     "avg_launch_ms": 2 * sm_ms,
+                     "note": "one launch = two full red+black sweeps (temporal blocking); traffic = HBM bytes per "
+                             "launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/traffic_latest.json"},
         "rocm_stack": _lib.bound_libs(L),
     }
     if world == 1 and not args.no_cpu_baseline:
