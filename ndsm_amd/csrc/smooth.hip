@@ -53,6 +53,43 @@ __global__ __launch_bounds__(256) void rbgs3_color(double *__restrict__ u, const
   u[lin3(i, j, k, nx, ny)] = g.w1 * unew;
 }
 
+// Small 3-D levels (<= 16^3 points): all `nsweeps` sweeps in ONE launch of ONE
+// workgroup.  The level is L2-resident and a colour pass is shorter than a kernel
+// boundary, so two launches per sweep are pure launch latency; inside a single
+// workgroup __syncthreads() orders the colour passes (global writes of a block are
+// visible to the block after the barrier).  Same update expression as rbgs3_color.
+__global__ __launch_bounds__(1024) void rbgs3_small(double *__restrict__ u, const double *__restrict__ rhs,
+                                                    ndsmk_grid g, int nsweeps) {
+  const int nx = g.n[0], ny = g.n[1];
+  const int mx = g.ub[0] - g.lb[0] + 1, my = g.ub[1] - g.lb[1] + 1, mz = g.ub[2] - g.lb[2] + 1;
+  const int half = (mx + 1) / 2;
+  const int total = half * my * mz;
+  for (int sw = 0; sw < nsweeps; ++sw) {
+    for (int pass = 0; pass < 2; ++pass) {
+      const int par = (g.first_par + pass) & 1;
+      for (int p = threadIdx.x; p < total; p += blockDim.x) {
+        const int t = p % half, j = g.lb[1] + (p / half) % my, k = g.lb[2] + p / (half * my);
+        const int i0 = g.lb[0] + ((((g.lb[0] + j + k) & 1) != par) ? 1 : 0);
+        const int i = i0 + 2 * t;
+        if (i > g.ub[0]) continue;
+        int xl = i - 1, xh = i + 1, yl = j - 1, yh = j + 1, zl = k - 1, zh = k + 1;
+        if (xl < 0) xl = 1;
+        if (xh > nx - 1) xh = nx - 2;
+        if (yl < 0) yl = 1;
+        if (yh > ny - 1) yh = ny - 2;
+        if (zl < 0) zl = 1;
+        if (zh > g.n[2] - 1) zh = g.n[2] - 2;
+        const double unew = (u[lin3(xh, j, k, nx, ny)] + u[lin3(xl, j, k, nx, ny)]) * g.w[0] +
+                            (u[lin3(i, yh, k, nx, ny)] + u[lin3(i, yl, k, nx, ny)]) * g.w[1] +
+                            (u[lin3(i, j, zh, nx, ny)] + u[lin3(i, j, zl, nx, ny)]) * g.w[2] -
+                            (rhs ? rhs[lin3(i, j, k, nx, ny)] : 0.0);
+        u[lin3(i, j, k, nx, ny)] = g.w1 * unew;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // 2-D colour pass (generic N-D path of the reference specialised to ndim = 2):
 // red = (i+j) even in either index base (ndsm_poisson.f90:499-501).
 __global__ __launch_bounds__(256) void rbgs2_color(double *__restrict__ u, const double *__restrict__ rhs,
@@ -92,6 +129,13 @@ extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, double *ualt, const 
   if (mx <= 0 || my <= 0 || (g.ndim == 3 && mz <= 0)) return 0;  // nothing to update
   double *const u_entry = u;
   if (result_in_alt) *result_in_alt = 0;
+  // small 3-D level: every sweep in one single-workgroup launch
+  if (g.ndim == 3 && variant == 0 && !g.all_neumann && npts <= 4096 && g.k0 == 0 && g.zown0 == 0 &&
+      g.zown1 == g.n[2] && nsweeps > 0) {
+    hipLaunchKernelGGL(rbgs3_small, dim3(1), dim3(1024), 0, s, u, rhs, g, nsweeps);
+    NDSM_LAUNCH_CHECK();
+    return 0;
+  }
   for (int sw = 0; sw < nsweeps; ++sw) {
     if (g.ndim == 3) {
       bool done = false;

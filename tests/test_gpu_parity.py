@@ -378,3 +378,33 @@ def test_slab_world_bitwise(hip, ns, nranks):
     assert (ierr2, nc2, du2) == (ierr, nc, du) and list(hist2) == list(hist)
     assert np.array_equal(W.download(hip.BUF_U), uref)
     W.close()
+
+
+def test_reference_quirks(hip, port):
+    """Q3' (returned ierr = flag of the last 2-D face solve; the 3-D flags are additive in iopt[8])
+    and Q2 (the Az solve always smooths with ms = 5) through the reference entry point."""
+    import ctypes
+    import ndsm_amd
+    x, y, z, A1, b1 = analytic_case(24)
+    b = b1.copy()
+    b[2, -1, :, :] = 0.0                       # B.n = 0 on the top face: its chi solve converges at once
+    ierr, A, B = ndsm_amd.vector_potential(x, y, z, b, ncycles_max=2)
+    ierr_o, A_o, B_o, io_o, _ = port.vector_potential(x, y, z, b, ncycles_max=2)
+    assert ierr == ierr_o == 0
+    assert np.abs(A - A_o).max() <= 1e-11 * np.abs(A_o).max()
+    # additive slot: which 3-D solves missed vc_tol
+    L = ndsm_amd.load_library()
+    ns = np.array(b.shape[::-1], dtype=np.intc)
+    io = np.zeros(16, dtype=np.intc)
+    ro = np.zeros(16)
+    io[0], io[1], io[6], io[7] = 5, 2, 1, 10000
+    ro[0], ro[1] = 1e-10, 1e-13
+    Aq, Bq = np.zeros(b.size), b.ravel().copy()
+    f = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))  # noqa: E731
+    rc = L.ndsm_vector_solve(ctypes.c_size_t(b.size), ns.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                             io.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), f(ro), f(x), f(y), f(z), f(Aq), f(Bq))
+    assert rc == 0 and io[3] == 0 and (io[L.get_iopt_fail3d()] & 0b011) == 0b011 and ro[L.get_ropt_tim()] > 0
+    # Q2: ms = 3 for Ax, Ay but 5 for Az -> identical to the oracle (which hard-codes the same)
+    ierr, A, B = ndsm_amd.vector_potential(x, y, z, b1.copy(), ms=3)
+    ierr_o, A_o, B_o, _, _ = port.vector_potential(x, y, z, b1, ms=3)
+    assert ierr == ierr_o and np.abs(A - A_o).max() <= 1e-11 * np.abs(A_o).max()
