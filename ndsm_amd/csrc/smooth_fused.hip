@@ -178,6 +178,56 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
     }
   }
 
+  // ---- per-slot constants of the z loop (byte offsets into an LDS plane) ----
+  // The loop body is issue bound, not bandwidth bound: with few slots per thread
+  // (HOIST) everything that does not depend on k is computed once and kept in
+  // registers; with many slots it is rematerialised per iteration instead (the
+  // registers are needed for the plane windows).
+  struct SC {
+    int lo;      // pair's first element
+    int yl, yh;  // signed row deltas to the y neighbours (mirrored at the physical faces)
+    int go;      // offset of the pair inside a global plane
+    int fl;      // bit 0 in-domain, 1 owned, 2/3 element 0/1 inside the x-y update bounds,
+                 // 4/5 element 0/1 mirrors its outer x neighbour, 6 parity base
+    int r0, r1;  // ring of element 0 / 1: stage t may update it iff ring > t
+  };
+  auto make_sc = [&](int tid_, int s) {
+    const SlotT q(tid_, s, x0, y0, nx, ny);
+    SC c;
+    c.lo = 8 * q.lo;
+    c.go = q.i + nx * q.j;
+    c.yl = (q.j == 0) ? 8 * TXH : -8 * TXH;
+    c.yh = (q.j == ny - 1) ? -8 * TXH : 8 * TXH;
+    const bool yin = q.j >= g.lb[1] && q.j <= g.ub[1];
+    // rows whose y neighbours fall outside the loaded tile can never be updated: ring 0
+    const bool yok = q.lj + (q.j == 0 ? 1 : -1) >= 0 && q.lj + (q.j == ny - 1 ? -1 : 1) < TYH;
+    int fl = (q.in ? 1 : 0) | (q.own ? 2 : 0);
+    fl |= (yin && q.i >= g.lb[0] && q.i <= g.ub[0]) ? 4 : 0;
+    fl |= (yin && q.i + 1 >= g.lb[0] && q.i + 1 <= g.ub[0]) ? 8 : 0;
+    fl |= (q.i == 0) ? 16 : 0;
+    fl |= (q.i + 1 == nx - 1) ? 32 : 0;
+    fl |= ((q.i + q.j + g.k0 + fp) & 1) ? 64 : 0;
+    c.fl = fl;
+    const int ry = min(openyl ? q.lj : BIG, openyh ? TYH - 1 - q.lj : BIG);
+    int r0 = min(min(openxl ? q.li : BIG, openxh ? TXH - 1 - q.li : BIG), ry);
+    int r1 = min(min(openxl ? q.li + 1 : BIG, openxh ? TXH - 2 - q.li : BIG), ry);
+    // the outer x neighbour must be in the tile unless it is mirrored
+    if (!(fl & 16) && q.li - 1 < 0) r0 = 0;
+    if (!(fl & 32) && q.li + 2 >= TXH) r1 = 0;
+    if (!yok) r0 = r1 = 0;
+    c.r0 = r0;
+    c.r1 = r1;
+    return c;
+  };
+  constexpr bool HOIST = NS <= 2;
+  SC scs[HOIST ? NS : 1];
+  if (HOIST) {
+#pragma unroll
+    for (int s = 0; s < (HOIST ? NS : 1); ++s) scs[s] = make_sc(tid, s);
+  }
+  char *const ldsb = reinterpret_cast<char *>(lds);
+#define LDSD(off) (*reinterpret_cast<double *>(ldsb + (off)))
+
   // ---- prologue: plane ks into its LDS buffer, plane ks+1 into registers ----
   {
     d2 c0[NS];
@@ -200,56 +250,66 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 
   const int klast = ze + NST - 2;  // iteration in which the last stage reaches plane ze-1
   for (int k = ks; k <= klast; ++k) {
-    const int kg = k + g.k0;
-    // make the thread index opaque once per iteration: the slot geometry is then
-    // recomputed (a few integer ops) instead of being kept live across the loop
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
+    // !HOIST: make the thread index opaque once per iteration so that the slot
+    // constants are recomputed here instead of being kept live across the loop
+    int tidk = tid0;
+    if (!HOIST) asm volatile("" : "+v"(tidk));
     // request plane k+2 of u and plane k+1 of rhs before touching plane k
-    if (k + 2 <= ke) NDSM_LOAD_PLANE(u, k + 2, nn);
-    if (!RHS0 && k + 1 <= ke) NDSM_LOAD_PLANE(rhs, k + 1, rn);
+    if (k + 2 <= ke) {
+      const double *pk = u + sz * (size_t)(k + 2);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const SC c = HOIST ? scs[HOIST ? s : 0] : make_sc(tidk, s);
+        if (c.fl & 1) nn[s] = ld2(pk + c.go);
+      }
+    }
+    if (!RHS0 && k + 1 <= ke) {
+      const double *pk = rhs + sz * (size_t)(k + 1);
+#pragma unroll
+      for (int s = 0; s < (RHS0 ? 1 : NS); ++s) {
+        const SC c = HOIST ? scs[HOIST ? s : 0] : make_sc(tidk, s);
+        if (c.fl & 1) rn[s] = ld2(pk + c.go);
+      }
+    }
 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const SlotT q(tid, s, x0, y0, nx, ny);
-      if (!q.in) continue;
+      const SC c = HOIST ? scs[HOIST ? s : 0] : make_sc(tidk, s);
+      const int fl = c.fl;
+      if (!(fl & 1)) continue;
       // the element every stage of this iteration updates in this pair
-      const int e = (((q.i + q.j + kg) & 1) == fp) ? 0 : 1;
-      const int ii = q.i + e, lii = q.li + e;
-      const bool xmir = (e == 0) ? (ii == 0) : (ii == nx - 1);
-      const int lxn = (e == 0) ? q.li - 1 : q.li + 2;
-      const int ljl = (q.j == 0) ? q.lj + 1 : q.lj - 1;
-      const int ljh = (q.j == ny - 1) ? q.lj - 1 : q.lj + 1;
-      const bool inb = ii >= g.lb[0] && ii <= g.ub[0] && q.j >= g.lb[1] && q.j <= g.ub[1];
-      // distance to the nearest tile edge that is not the physical boundary:
-      // stage t may update a point only if that distance is > t
-      const int ring = min(min(openxl ? lii : BIG, openxh ? TXH - 1 - lii : BIG),
-                           min(openyl ? q.lj : BIG, openyh ? TYH - 1 - q.lj : BIG));
+      const int e = ((fl >> 6) + k) & 1;
+      const int eB = c.lo + 8 * e;               // the element, its pair partner, its outer x neighbour
+      const int oB = c.lo + 8 - 8 * e;
+      const int xB = e ? c.lo + 16 : c.lo - 8;
+      const bool xmir = (fl >> (4 + e)) & 1;
+      const bool inb = (fl >> (2 + e)) & 1;
+      const int ring = e ? c.r1 : c.r0;
       double zplus = pick(nxt[s], e);  // plane k+1, untouched by any stage yet
 
 #pragma unroll
       for (int t = 0; t < NST; ++t) {
         const int p = k - t;  // plane of this stage
-        // stage t covers planes [zs-(NST-1-t), ze-1+(NST-1-t)] of the chunk
+        // stage t covers planes [zs-(NST-1-t), ze-1+(NST-1-t)] of the chunk (uniform test)
         const bool act = p >= max(zs - (NST - 1 - t), 0) && p <= min(ze - 1 + (NST - 1 - t), nz - 1);
-        if (!act) continue;  // uniform; zplus is not needed by later stages either (their planes are inactive too or re-read)
-        double *buf = lds + ((p % NST) * PLANE);
-        double cur = buf[q.lo + e];
+        if (!act) continue;
+        const int bB = (p & (NST - 1)) * (PLANE * 8);
+        double cur = LDSD(bB + eB);
         if (inb && p >= g.lb[2] && p <= g.ub[2] && ring > t) {
           const int pg = p + g.k0;
-          const double other = buf[q.lo + 1 - e];
-          const double xn = xmir ? other : buf[q.lj * TXH + lxn];
+          const double other = LDSD(bB + oB);
+          const double xn = xmir ? other : LDSD(bB + xB);
           const double xs = (e == 0) ? (other + xn) : (xn + other);  // u(xh) + u(xl)
-          const double ys = buf[ljh * TXH + lii] + buf[ljl * TXH + lii];
+          const double ys = LDSD(bB + eB + c.yh) + LDSD(bB + eB + c.yl);
           // plane p-1: its LDS copy, or (last stage) the saved final element
-          const double zminus = (t < NST - 1) ? lds[(((p - 1 + NST) % NST) * PLANE) + q.lo + e] : mLe[s];
+          const double zminus = (t < NST - 1) ? LDSD(((p - 1) & (NST - 1)) * (PLANE * 8) + eB) : mLe[s];
           const double zhv = (pg == g.nzg - 1) ? zminus : zplus;
           const double zlv = (pg == 0) ? zplus : zminus;
           const double zsum = zhv + zlv;
           const double rr = RHS0 ? 0.0 : pick(rw[RHS0 ? 0 : s][RHS0 ? 0 : t], e);
           const double unew = xs * g.w[0] + ys * g.w[1] + zsum * g.w[2] - rr;
           cur = g.w1 * unew;
-          buf[q.lo + e] = cur;
+          LDSD(bB + eB) = cur;
         }
         zplus = cur;  // z+1 neighbour of the next stage's plane
       }
@@ -258,8 +318,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       // iteration's last stage needs from it (its other element, already final)
       const int pf = k - (NST - 1);
       if (pf >= ks) {
-        const d2 fin = ld2(lds + ((pf % NST) * PLANE) + q.lo);
-        if (pf >= zs && pf < ze && q.own) st2(uout + sz * (size_t)pf + (q.i + nx * q.j), fin);
+        const d2 fin = ld2(reinterpret_cast<const double *>(ldsb + (pf & (NST - 1)) * (PLANE * 8) + c.lo));
+        if (pf >= zs && pf < ze && (fl & 2)) st2(uout + sz * (size_t)pf + c.go, fin);
         mLe[s] = pick(fin, 1 - e);
       }
     }
@@ -268,11 +328,11 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 
     // ---- plane k+1 takes the LDS buffer of plane k-NST+1; shift the windows ----
     {
-      double *bn = lds + (((k + 1) % NST) * PLANE);
+      char *bn = ldsb + ((k + 1) & (NST - 1)) * (PLANE * 8);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const SlotT q(tid, s, x0, y0, nx, ny);
-        if (k + 1 <= ke && q.live) st2(bn + q.lo, nxt[s]);
+        const SC c = HOIST ? scs[HOIST ? s : 0] : make_sc(tidk, s);
+        if (k + 1 <= ke && tid0 + NT * s < NPAIR) st2(reinterpret_cast<double *>(bn + c.lo), nxt[s]);
         nxt[s] = nn[s];
       }
       if (!RHS0) {
@@ -286,6 +346,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
     }
     __syncthreads();
   }
+#undef LDSD
 #undef NDSM_LOAD_PLANE
 }
 
