@@ -112,7 +112,8 @@ int ndsm_hip_mg_download(void *handle, int level, int which, double *host);
 int ndsm_hip_mg_zero_rhs(void *handle);
 /* op: 0 relax (count sweeps), 1 residual -> scratch, 2 restrict scratch(level) -> rhs(level+1)
  * and zero u(level+1), 3 u(level) += P u(level+1), 4 coarsest-grid solve, 5/6 relax forced to
- * the two-pass / fused kernel.  Asynchronous. */
+ * the two-pass / fused kernel, 8 relax (count sweeps) then residual -> scratch with the last
+ * sweep and the residual in one launch where the level allows (9: or fail).  Asynchronous. */
 int ndsm_hip_mg_op(void *handle, int op, int level, int count);
 int ndsm_hip_mg_vcycle(void *handle, int ncycles);   /* asynchronous, no convergence test */
 /* V-cycles to vc_tol: returns 0 converged, 1 not, >= 9001 error */

@@ -13,6 +13,7 @@ namespace ndsm {
 // one library stream; every kernel, copy and RCCL call is ordered on it
 hipStream_t stream();
 bool ready();
+int cu_count();
 int fail(int code, const char *what, const char *file, int line);
 int not_ready(const char *file, int line);
 

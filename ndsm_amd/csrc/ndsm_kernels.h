@@ -101,6 +101,9 @@ int ndsmk_timer_stop(double *ms);           /* blocking; elapsed between start a
  * its two pointers (result_in_alt == NULL: it is copied back into u). */
 int ndsmk_relax(const ndsmk_grid *g, double *u, double *ualt, const double *rhs, int nsweeps, int variant,
                 int *result_in_alt);
+/* nsweeps sweeps, then r = rhs - L u of the result (fused into the last sweep's launch where possible) */
+int ndsmk_relax_residual(const ndsmk_grid *g, double *u, double *ualt, const double *rhs, double *r, int nsweeps,
+                         int variant, int *result_in_alt);
 /* r = rhs - L u, zero on Dirichlet faces (ndsm_optimized.f90:346-447 / ndsm_poisson.f90:280-353) */
 int ndsmk_residual(const ndsmk_grid *g, const double *u, const double *rhs, double *r);
 /* rhs_c = R r_f ; also u_c = 0 if u_c != NULL (ndsm_multigrid_core.f90:551,557-558) */

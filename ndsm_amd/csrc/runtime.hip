@@ -13,6 +13,7 @@ namespace {
 struct Runtime {
   bool up = false;
   int device = -1;
+  int ncu = 256;  // compute units of the device (MI355X: 256)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = "no error";
@@ -27,6 +28,7 @@ namespace ndsm {
 
 hipStream_t stream() { return g_rt.stream; }
 bool ready() { return g_rt.up; }
+int cu_count() { return g_rt.ncu > 0 ? g_rt.ncu : 256; }
 
 int fail(int code, const char *what, const char *file, int line) {
   const char *base = std::strrchr(file, '/');
@@ -79,6 +81,7 @@ int ndsmk_init(int device) {
   NDSM_HIP(hipEventCreate(&g_rt.ev0));
   NDSM_HIP(hipEventCreate(&g_rt.ev1));
   g_rt.device = device;
+  g_rt.ncu = prop.multiProcessorCount;
   g_rt.up = true;
   return 0;
 }

@@ -15,7 +15,7 @@
 
 namespace ndsm {
 int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
-                       bool force, int *sweeps_done);
+                       bool force, int *sweeps_done, double *rout, int *res_done);
 int launch_mean_shift(double *u, int64_t n);
 }
 
@@ -114,9 +114,10 @@ __global__ __launch_bounds__(256) void rbgs2_color(double *__restrict__ u, const
 
 }  // namespace
 
-extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, double *ualt, const double *rhs, int nsweeps,
-                           int variant, int *result_in_alt) {
+static int relax_impl(const ndsmk_grid *gp, double *u, double *ualt, const double *rhs, int nsweeps, int variant,
+                      int *result_in_alt, double *rout, int *res_done) {
   NDSM_REQUIRE_READY();
+  if (res_done) *res_done = 0;
   const ndsmk_grid g = *gp;
   NDSM_CHECK_ARG(g.ndim == 2 || g.ndim == 3);
   NDSM_CHECK_ARG(g.n[0] >= 2 && g.n[1] >= 2 && (g.ndim == 2 ? g.n[2] == 1 : g.n[2] >= 2));
@@ -142,7 +143,9 @@ extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, double *ualt, const 
       if (variant != 1) {
         // all-Neumann levels shift the mean after EVERY sweep: one sweep per pass there
         int ndone = 0;
-        int rc = ndsm::launch_rbgs3_fused(g, u, ualt, rhs, g.all_neumann ? 1 : nsweeps - sw, variant == 2, &ndone);
+        // the residual rides on the last sweep (not on all-Neumann levels: the mean shift comes in between)
+        int rc = ndsm::launch_rbgs3_fused(g, u, ualt, rhs, g.all_neumann ? 1 : nsweeps - sw, variant == 2, &ndone,
+                                          g.all_neumann ? nullptr : rout, res_done);
         if (rc) return rc;
         done = ndone > 0;
         if (done) {  // the sweeps landed in the other array
@@ -188,4 +191,26 @@ extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, double *ualt, const 
     }
   }
   return 0;
+}
+
+extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, double *ualt, const double *rhs, int nsweeps,
+                           int variant, int *result_in_alt) {
+  return relax_impl(gp, u, ualt, rhs, nsweeps, variant, result_in_alt, nullptr, nullptr);
+}
+
+// nsweeps sweeps followed by r = rhs - L u: where the fused kernel covers the level
+// the residual is produced by the launch of the last sweep, otherwise by residual.hip.
+// variant 2 (tests): the fused sweep+residual launch or an error.
+extern "C" int ndsmk_relax_residual(const ndsmk_grid *gp, double *u, double *ualt, const double *rhs, double *r,
+                                    int nsweeps, int variant, int *result_in_alt) {
+  NDSM_CHECK_ARG(r != nullptr && result_in_alt != nullptr && (variant == 0 || variant == 2));
+  int res_done = 0;
+  int rc = relax_impl(gp, u, ualt, rhs, nsweeps, variant, result_in_alt, r, &res_done);
+  if (rc) return rc;
+  if (!res_done) {
+    if (variant == 2)
+      return ndsm::fail(NDSMK_EARG, "fused sweep + residual does not cover this level", __FILE__, __LINE__);
+    rc = ndsmk_residual(gp, *result_in_alt ? ualt : u, rhs, r);
+  }
+  return rc;
 }

@@ -30,6 +30,7 @@
 #include "common.hpp"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -69,7 +70,7 @@ __device__ __forceinline__ double pick(const d2 a, int e) { return e ? a.y : a.x
 
 // geometry of slot s of this thread, recomputed where needed (cheap integer
 // ops) instead of being held in registers across the z loop
-template <int TXH, int TYH, int NT, int HALO>
+template <int TXH, int TYH, int NT, int HX, int HY>
 struct Slot {
   int li, lj, i, j, lo;
   bool live, in, own;
@@ -82,7 +83,7 @@ struct Slot {
     j = y0 + lj;
     live = p < NPX * TYH;
     in = live && i >= 0 && i + 1 < nx && j >= 0 && j < ny;
-    own = in && li >= HALO && li < TXH - HALO && lj >= HALO && lj < TYH - HALO;
+    own = in && li >= HX && li < TXH - HX && lj >= HY && lj < TYH - HY;
     lo = live ? li + TXH * lj : 0;
   }
 };
@@ -107,18 +108,28 @@ struct Slot {
 //     threads ever touch the same LDS word.
 // Plane p lives in LDS buffer p mod 2S; the incoming plane k+1 replaces plane
 // k-2S+1, which the last stage has just finished and stored.
-template <int S, int TXH, int TYH, int NT, int WPS, bool RHS0>
+//
+// RES: one more pipeline stage evaluates the residual r = rhs - L u of the swept
+// field (same expression as residual.hip) on plane k - 2S, one plane behind the
+// store, and writes it to rout - the sweep + residual pair at the bottom of the
+// V-cycle's descent then moves 24 (Laplace) instead of 16 + 16 B per point.  The
+// stage needs plane k-2S with its in-plane neighbours (one more LDS buffer) and
+// the thread's own pairs of planes k-2S+1 and k-2S-1 (registers); halo and chunk
+// warm-up grow by one.
+template <int S, int TXH, int TYH, int NT, int WPS, bool RHS0, bool RES>
 __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restrict__ u, double *__restrict__ uout,
-                                                         const double *__restrict__ rhs, ndsmk_grid g,
-                                                         FusedPlan pl) {
-  constexpr int NST = 2 * S;  // stages = LDS planes = halo width
+                                                         const double *__restrict__ rhs, double *__restrict__ rout,
+                                                         ndsmk_grid g, FusedPlan pl) {
+  constexpr int NST = 2 * S;                 // smoothing stages
+  constexpr int NSTG = RES ? NST + 1 : NST;  // pipeline depth = LDS planes = halo width
   constexpr int NPX = TXH / 2;
   constexpr int NPAIR = NPX * TYH;
   constexpr int NS = (NPAIR + NT - 1) / NT;
-  constexpr int TXI = TXH - 2 * NST, TYI = TYH - 2 * NST;
+  constexpr int HX = (NSTG + 1) & ~1;        // x halo: even, pairs stay 16-byte aligned
+  constexpr int TXI = TXH - 2 * HX, TYI = TYH - 2 * NSTG;
   constexpr int PLANE = TXH * TYH;
   constexpr int BIG = 1 << 20;
-  using SlotT = Slot<TXH, TYH, NT, NST>;
+  using SlotT = Slot<TXH, TYH, NT, HX, NSTG>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
   // ---- which (tile, chunk): consecutive y tiles share an XCD ---------
@@ -131,11 +142,11 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
   const int cz = t2 / pl.ntx;
 
   const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
-  const int x0 = tx * TXI - NST, y0 = ty * TYI - NST;
+  const int x0 = tx * TXI - HX, y0 = ty * TYI - NSTG;
   const int zs = g.zown0 + cz * pl.zc;
   const int ze = min(zs + pl.zc, g.zown1);
-  const int ks = max(zs - NST, 0);
-  const int ke = min(ze - 1 + NST, nz - 1);  // last plane ever loaded
+  const int ks = max(zs - NSTG, 0);
+  const int ke = min(ze - 1 + NSTG, nz - 1);  // last plane ever loaded
   const size_t sz = (size_t)nx * (size_t)ny;
   const int tid0 = (int)threadIdx.x;
   const int tid = tid0;
@@ -161,20 +172,27 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
   //   mLe = the element of plane k-2S (final) the last stage needs as z-1 neighbour
   //   rw[t] = rhs of plane k-t, rn = rhs of plane k+1 (in flight)
   d2 nxt[NS], nn[NS];
-  d2 rw[RHS0 ? 1 : NS][RHS0 ? 1 : NST], rn[RHS0 ? 1 : NS];
-  double mLe[NS];
+  //   RES: f1 / f2 = the final pairs of planes k-2S and k-2S-1
+  d2 rw[RHS0 ? 1 : NS][RHS0 ? 1 : NSTG], rn[RHS0 ? 1 : NS];
+  double mLe[RES ? 1 : NS];
+  d2 f1[RES ? NS : 1], f2[RES ? NS : 1];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     nxt[s].x = nxt[s].y = 0.0;
     nn[s].x = nn[s].y = 0.0;
-    mLe[s] = 0.0;
+    if (RES) {
+      f1[RES ? s : 0].x = f1[RES ? s : 0].y = 0.0;
+      f2[RES ? s : 0].x = f2[RES ? s : 0].y = 0.0;
+    } else {
+      mLe[RES ? 0 : s] = 0.0;
+    }
   }
   if (!RHS0) {
 #pragma unroll
     for (int s = 0; s < (RHS0 ? 1 : NS); ++s) {
       rn[s].x = rn[s].y = 0.0;
 #pragma unroll
-      for (int t = 0; t < (RHS0 ? 1 : NST); ++t) rw[s][t].x = rw[s][t].y = 0.0;
+      for (int t = 0; t < (RHS0 ? 1 : NSTG); ++t) rw[s][t].x = rw[s][t].y = 0.0;
     }
   }
 
@@ -239,7 +257,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rw[s][0] = r0[s];
     }
     if (ks + 1 <= ke) NDSM_LOAD_PLANE(u, ks + 1, nxt);
-    double *B0 = lds + (ks % NST) * PLANE;
+    double *B0 = lds + (ks % NSTG) * PLANE;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const SlotT q(tid, s, x0, y0, nx, ny);
@@ -248,8 +266,21 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
   }
   __syncthreads();
 
-  const int klast = ze + NST - 2;  // iteration in which the last stage reaches plane ze-1
+  const int klast = ze + NSTG - 2;  // iteration in which the last stage reaches plane ze-1
+  int kb = ks % NSTG;               // LDS buffer of plane k (RES: NSTG is not a power of two)
   for (int k = ks; k <= klast; ++k) {
+    // byte offset of the LDS buffer of plane k - d, -1 <= d <= NSTG
+    auto bufoff = [&](int d) {
+      int b;
+      if (RES) {
+        b = kb - d;
+        b = b < 0 ? b + NSTG : b;
+        b = b >= NSTG ? b - NSTG : b;
+      } else {
+        b = (k - d) & (NST - 1);
+      }
+      return b * (PLANE * 8);
+    };
     // !HOIST: make the thread index opaque once per iteration so that the slot
     // constants are recomputed here instead of being kept live across the loop
     int tidk = tid0;
@@ -291,9 +322,9 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       for (int t = 0; t < NST; ++t) {
         const int p = k - t;  // plane of this stage
         // stage t covers planes [zs-(NST-1-t), ze-1+(NST-1-t)] of the chunk (uniform test)
-        const bool act = p >= max(zs - (NST - 1 - t), 0) && p <= min(ze - 1 + (NST - 1 - t), nz - 1);
+        const bool act = p >= max(zs - (NSTG - 1 - t), 0) && p <= min(ze - 1 + (NSTG - 1 - t), nz - 1);
         if (!act) continue;
-        const int bB = (p & (NST - 1)) * (PLANE * 8);
+        const int bB = bufoff(t);
         double cur = LDSD(bB + eB);
         if (inb && p >= g.lb[2] && p <= g.ub[2] && ring > t) {
           const int pg = p + g.k0;
@@ -302,7 +333,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
           const double xs = (e == 0) ? (other + xn) : (xn + other);  // u(xh) + u(xl)
           const double ys = LDSD(bB + eB + c.yh) + LDSD(bB + eB + c.yl);
           // plane p-1: its LDS copy, or (last stage) the saved final element
-          const double zminus = (t < NST - 1) ? LDSD(((p - 1) & (NST - 1)) * (PLANE * 8) + eB) : mLe[s];
+          const double zminus = (t < NSTG - 1) ? LDSD(bufoff(t + 1) + eB) : mLe[RES ? 0 : s];
           const double zhv = (pg == g.nzg - 1) ? zminus : zplus;
           const double zlv = (pg == 0) ? zplus : zminus;
           const double zsum = zhv + zlv;
@@ -317,10 +348,39 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       // plane k-NST+1 has passed its last stage: store it, keep what the next
       // iteration's last stage needs from it (its other element, already final)
       const int pf = k - (NST - 1);
+      d2 fin;
+      fin.x = fin.y = 0.0;
       if (pf >= ks) {
-        const d2 fin = ld2(reinterpret_cast<const double *>(ldsb + (pf & (NST - 1)) * (PLANE * 8) + c.lo));
+        fin = ld2(reinterpret_cast<const double *>(ldsb + bufoff(NST - 1) + c.lo));
         if (pf >= zs && pf < ze && (fl & 2)) st2(uout + sz * (size_t)pf + c.go, fin);
-        mLe[s] = pick(fin, 1 - e);
+        if (!RES) mLe[RES ? 0 : s] = pick(fin, 1 - e);
+      }
+      if (RES) {
+        // residual of plane k-NST: centre f1, below f2, above fin (all final)
+        const int pr = k - NST;
+        const d2 cc = f1[RES ? s : 0], below = f2[RES ? s : 0];
+        if (pr >= zs && pr < ze && (fl & 2)) {
+          const int bR = bufoff(NST);
+          const double xl0 = (fl & 16) ? cc.y : LDSD(bR + c.lo - 8);
+          const double xh1 = (fl & 32) ? cc.x : LDSD(bR + c.lo + 16);
+          const d2 vl = ld2(reinterpret_cast<const double *>(ldsb + bR + c.lo + c.yl));
+          const d2 vh = ld2(reinterpret_cast<const double *>(ldsb + bR + c.lo + c.yh));
+          const int prg = pr + g.k0;
+          const d2 wl = (prg == 0) ? fin : below;
+          const d2 wh = (prg == g.nzg - 1) ? below : fin;
+          const bool inz = pr >= g.lb[2] && pr <= g.ub[2];
+          d2 rr;
+          rr.x = rr.y = 0.0;
+          if (!RHS0) rr = rw[RHS0 ? 0 : s][RHS0 ? 0 : NST];
+          const double v0 = (xl0 + cc.y) * g.w[0] + (vl.x + vh.x) * g.w[1] + (wl.x + wh.x) * g.w[2] - rr.x - cc.x * g.wc;
+          const double v1 = (cc.x + xh1) * g.w[0] + (vl.y + vh.y) * g.w[1] + (wl.y + wh.y) * g.w[2] - rr.y - cc.y * g.wc;
+          d2 res;
+          res.x = (inz && (fl & 4)) ? -v0 : 0.0;
+          res.y = (inz && (fl & 8)) ? -v1 : 0.0;
+          st2(rout + sz * (size_t)pr + c.go, res);
+        }
+        f2[RES ? s : 0] = cc;
+        f1[RES ? s : 0] = fin;
       }
     }
 
@@ -328,7 +388,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 
     // ---- plane k+1 takes the LDS buffer of plane k-NST+1; shift the windows ----
     {
-      char *bn = ldsb + ((k + 1) & (NST - 1)) * (PLANE * 8);
+      char *bn = ldsb + bufoff(-1);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const SC c = HOIST ? scs[HOIST ? s : 0] : make_sc(tidk, s);
@@ -339,58 +399,84 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 #pragma unroll
         for (int s = 0; s < (RHS0 ? 1 : NS); ++s) {
 #pragma unroll
-          for (int t = (RHS0 ? 1 : NST) - 1; t > 0; --t) rw[s][t] = rw[s][t - 1];
+          for (int t = (RHS0 ? 1 : NSTG) - 1; t > 0; --t) rw[s][t] = rw[s][t - 1];
           rw[s][0] = rn[s];
         }
       }
     }
+    kb = (kb + 1 == NSTG) ? 0 : kb + 1;
     __syncthreads();
   }
 #undef LDSD
 #undef NDSM_LOAD_PLANE
 }
 
-template <int S, int TXH, int TYH, int NT, int WPS>
-int launch_cfg(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int target_wgs) {
-  constexpr int NST = 2 * S;
-  constexpr int TXI = TXH - 2 * NST, TYI = TYH - 2 * NST;
+template <int S, int TXH, int TYH, int NT, int WPS, bool RES = false>
+int launch_cfg(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int target_wgs,
+               double *rout = nullptr) {
+  constexpr int NST = RES ? 2 * S + 1 : 2 * S;
+  constexpr int TXI = TXH - 2 * ((NST + 1) & ~1), TYI = TYH - 2 * NST;
   static_assert(TXI > 0 && TYI > 0 && (TXH % 2) == 0, "tile");
   FusedPlan pl;
   pl.ntx = (g.n[0] + TXI - 1) / TXI;
   pl.nty = (g.n[1] + TYI - 1) / TYI;
   const int tiles = pl.ntx * pl.nty;
-  // z chunks: enough work items to fill the chip, but chunks of >= 16 planes
-  int nzc = (target_wgs + tiles - 1) / tiles;
-  if (nzc < 1) nzc = 1;
   const int nzo = g.zown1 - g.zown0;  // owned planes
-  int zc = (nzo + nzc - 1) / nzc;
-  if (zc < 16) zc = 16 < nzo ? 16 : nzo;
-  pl.zc = zc;
-  pl.nzc = (nzo + zc - 1) / zc;
+  const size_t lds_bytes = sizeof(double) * NST * TXH * TYH;
+  static bool attr_set[2] = {false, false};
+  static int wgs_per_cu[2] = {1, 1};
+  const int v = rhs ? 0 : 1;
+  const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<S, TXH, TYH, NT, WPS, false, RES>)
+                         : reinterpret_cast<const void *>(rbgs3_fused_k<S, TXH, TYH, NT, WPS, true, RES>);
+  if (!attr_set[v]) {
+    NDSM_HIP(hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int occ = 1;
+    if (rhs)
+      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<S, TXH, TYH, NT, WPS, false, RES>, NT,
+                                                            lds_bytes));
+    else
+      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<S, TXH, TYH, NT, WPS, true, RES>, NT,
+                                                            lds_bytes));
+    wgs_per_cu[v] = occ > 0 ? occ : 1;
+    attr_set[v] = true;
+  }
+  // z chunks.  A workgroup walks its chunk plus NST warm-up planes on either side, and
+  // the chip runs ncu * wgs_per_cu workgroups at a time: pick the chunk count that
+  // minimises (rounds of workgroups) x (planes walked per workgroup).
+  int nzc;
+  if (target_wgs > 0) {
+    nzc = (target_wgs + tiles - 1) / tiles;
+    if (nzc < 1) nzc = 1;
+    int zc = (nzo + nzc - 1) / nzc;
+    if (zc < 16) zc = 16 < nzo ? 16 : nzo;
+    nzc = (nzo + zc - 1) / zc;
+  } else {
+    const int64_t slots = (int64_t)ndsm::cu_count() * wgs_per_cu[v];
+    int64_t best = -1;
+    nzc = 1;
+    for (int c = 1; c <= (nzo + 7) / 8; ++c) {
+      const int zc = (nzo + c - 1) / c;
+      const int cc = (nzo + zc - 1) / zc;
+      const int64_t rounds = ((int64_t)tiles * cc + slots - 1) / slots;
+      const int64_t cost = rounds * (zc + 2 * NST);
+      if (best < 0 || cost < best) {
+        best = cost;
+        nzc = cc;
+      }
+    }
+  }
+  pl.zc = (nzo + nzc - 1) / nzc;
+  pl.nzc = (nzo + pl.zc - 1) / pl.zc;
   pl.nwork = tiles * pl.nzc;
   const int nblk = ((pl.nwork + 7) / 8) * 8;
-  const size_t lds_bytes = sizeof(double) * NST * TXH * TYH;
-  // rhs == nullptr: the level's right-hand side is identically zero (level 1 of NDSM's
-  // Laplace problems, ndsm_vector_potential.f90:640-641): x - 0.0 == x exactly, so the
-  // variant that never loads rhs returns the same bits with 8 B/LUP less traffic
-  static bool attr_set[2] = {false, false};
-  if (rhs) {
-    auto kfn = rbgs3_fused_k<S, TXH, TYH, NT, WPS, false>;
-    if (!attr_set[0]) {
-      NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds_bytes));
-      attr_set[0] = true;
-    }
-    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(NT), lds_bytes, ndsm::stream(), u, uout, rhs, g, pl);
-  } else {
-    auto kfn = rbgs3_fused_k<S, TXH, TYH, NT, WPS, true>;
-    if (!attr_set[1]) {
-      NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds_bytes));
-      attr_set[1] = true;
-    }
-    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(NT), lds_bytes, ndsm::stream(), u, uout, rhs, g, pl);
-  }
+  if (rhs)
+    hipLaunchKernelGGL((rbgs3_fused_k<S, TXH, TYH, NT, WPS, false, RES>), dim3(nblk), dim3(NT), lds_bytes,
+                       ndsm::stream(), u, uout, rhs, rout, g, pl);
+  else  // the level's rhs is identically zero (level 1 of NDSM's Laplace problems,
+        // ndsm_vector_potential.f90:640-641): x - 0.0 == x exactly, so the variant that never
+        // loads rhs returns the same bits with 8 B/LUP less traffic
+    hipLaunchKernelGGL((rbgs3_fused_k<S, TXH, TYH, NT, WPS, true, RES>), dim3(nblk), dim3(NT), lds_bytes,
+                       ndsm::stream(), u, uout, rhs, rout, g, pl);
   NDSM_LAUNCH_CHECK();
   return 0;
 }
@@ -399,57 +485,73 @@ int launch_cfg(const ndsmk_grid &g, const double *u, double *uout, const double 
 
 namespace ndsm {
 
-// Development knob: NDSM_FUSED_CFG=<n> picks a tile configuration (default 0).
-static int fused_cfg() {
-  static int cfg = -1;
-  if (cfg < 0) {
+// Development knob: NDSM_FUSED_CFG=<two-sweep cfg>,<one-sweep cfg>,<sweep+residual cfg> picks
+// tile configurations (default 0,0,0; scripts/tune_smoother.py).
+static const int *fused_cfg() {
+  static int cfg[4] = {-1, 0, 0, 0};
+  if (cfg[0] < 0) {
+    cfg[0] = 0;
     const char *e = std::getenv("NDSM_FUSED_CFG");
-    cfg = e ? std::atoi(e) : 0;
+    for (int i = 0; e && i < 4; ++i) {
+      cfg[i] = std::atoi(e);
+      e = std::strchr(e, ',');
+      if (e) ++e;
+    }
   }
   return cfg;
 }
 
+// rout != nullptr: the caller wants the residual of the swept field as well.  It is
+// produced (and *res_done set) only by the launch that performs the LAST of the
+// max_sweeps sweeps, i.e. when this call runs a single sweep with max_sweeps == 1.
 int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
-                       bool force, int *sweeps_done) {
+                       bool force, int *sweeps_done, double *rout, int *res_done) {
   *sweeps_done = 0;
+  if (res_done) *res_done = 0;
   if (!uout || g.ndim != 3 || (g.n[0] & 1) || g.n[0] < 16 || g.n[1] < 16 || g.zown1 - g.zown0 < 8) return 0;
   // a z-streaming workgroup walks >= 16 planes serially: with fewer than ~one
   // workgroup per CU the sweep is latency bound and the two colour passes win
   const int64_t npts = (int64_t)g.n[0] * g.n[1] * (g.zown1 - g.zown0);
   const bool slab = g.zown1 - g.zown0 != g.n[2];
   if (npts < (int64_t)6 * 1024 * 1024 && !slab && !force) return 0;
-  // Tile choice measured on MI355X (scripts/tune_smoother.py): the sweep is bound
-  // by fabric traffic (halo rows + chunk warm-up planes), and more, shorter chunks
-  // beat fewer, longer ones up to ~8 work items per CU.
+  // Tile choices measured on MI355X (scripts/tune_smoother.py); launch_cfg picks the z chunking.
   int rc;
-  const int cfg = fused_cfg();
-  const bool two = max_sweeps >= 2 && !slab && cfg != 99;  // slabs exchange 2 ghost planes per sweep
+  const int *cfg = fused_cfg();
+  const int tgt = cfg[3] > 0 ? cfg[3] : 0;  // > 0: that many work items instead of launch_cfg's own choice
+  const bool big = npts >= (int64_t)64 * 1024 * 1024;
+  const bool res = rout && res_done && !slab && cfg[2] != 9;
+  // two sweeps per pass - not for slabs (2 ghost planes are exchanged per sweep), and not
+  // for the last two sweeps when the residual is wanted (it rides on a one-sweep pass)
+  const bool two = max_sweeps >= 2 && !slab && cfg[0] != 9 && !(res && max_sweeps == 2);
   if (two) {
-    switch (cfg) {
-      case 21: rc = launch_cfg<2, 136, 30, 1024, 4>(g, u, uout, rhs, 512); break;
-      case 22: rc = launch_cfg<2, 136, 30, 1024, 4>(g, u, uout, rhs, 1024); break;
-      case 23: rc = launch_cfg<2, 136, 22, 768, 4>(g, u, uout, rhs, 768); break;
-      case 24: rc = launch_cfg<2, 72, 30, 512, 4>(g, u, uout, rhs, 1024); break;
-      default: rc = launch_cfg<2, 136, 30, 1024, 4>(g, u, uout, rhs, 768); break;
+    switch (cfg[0]) {
+      case 3: rc = launch_cfg<2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;
+      case 4: rc = launch_cfg<2, 72, 30, 512, 4>(g, u, uout, rhs, tgt); break;
+      case 5: rc = launch_cfg<2, 72, 28, 512, 4>(g, u, uout, rhs, tgt); break;
+      default: rc = launch_cfg<2, 136, 30, 1024, 4>(g, u, uout, rhs, tgt); break;
     }
     if (rc) return rc;
     *sweeps_done = 2;
     return 0;
   }
-  if (cfg == 0 || cfg >= 20) {
-    if (npts >= (int64_t)64 * 1024 * 1024)
-      rc = launch_cfg<1, 132, 31, 512, 4>(g, u, uout, rhs, 2048);
-    else
-      rc = launch_cfg<1, 68, 30, 256, 4>(g, u, uout, rhs, 1024);
-  } else {
-    switch (cfg) {
-      case 1: rc = launch_cfg<1, 132, 62, 1024, 4>(g, u, uout, rhs, 1024); break;
-      case 2: rc = launch_cfg<1, 68, 30, 256, 4>(g, u, uout, rhs, 1024); break;
-      case 3: rc = launch_cfg<1, 132, 31, 1024, 8>(g, u, uout, rhs, 2048); break;
-      case 4: rc = launch_cfg<1, 68, 60, 512, 4>(g, u, uout, rhs, 1024); break;
-      case 5: rc = launch_cfg<1, 132, 31, 512, 4>(g, u, uout, rhs, 1024); break;
-      default: rc = launch_cfg<1, 132, 31, 512, 4>(g, u, uout, rhs, 2048); break;
+  if (res && max_sweeps == 1) {
+    switch (cfg[2]) {
+      case 1: rc = (launch_cfg<1, 136, 30, 1024, 4, true>(g, u, uout, rhs, tgt, rout)); break;
+      case 4: rc = (launch_cfg<1, 72, 30, 512, 4, true>(g, u, uout, rhs, tgt, rout)); break;
+      default: rc = (launch_cfg<1, 136, 22, 768, 4, true>(g, u, uout, rhs, tgt, rout)); break;
     }
+    if (rc) return rc;
+    *sweeps_done = 1;
+    *res_done = 1;
+    return 0;
+  }
+  switch (cfg[1] ? cfg[1] : (big ? 7 : 8)) {
+    case 1: rc = launch_cfg<1, 132, 62, 1024, 4>(g, u, uout, rhs, tgt); break;
+    case 2: rc = launch_cfg<1, 68, 30, 256, 4>(g, u, uout, rhs, tgt); break;
+    case 4: rc = launch_cfg<1, 68, 60, 512, 4>(g, u, uout, rhs, tgt); break;
+    case 5: rc = launch_cfg<1, 132, 31, 512, 4>(g, u, uout, rhs, tgt); break;
+    case 8: rc = launch_cfg<1, 132, 23, 768, 4>(g, u, uout, rhs, tgt); break;
+    default: rc = launch_cfg<1, 132, 31, 1024, 4>(g, u, uout, rhs, tgt); break;
   }
   if (rc) return rc;
   *sweeps_done = 1;

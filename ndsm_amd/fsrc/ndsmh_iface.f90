@@ -125,6 +125,16 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_relax_residual(g, u, ualt, rhs, r, nsweeps, variant, result_in_alt) &
+        bind(c, name="ndsmk_relax_residual") result(rc)
+      import :: ndsmk_grid, c_ptr, c_int
+      type(ndsmk_grid), intent(in) :: g
+      type(c_ptr), value :: u, ualt, rhs, r
+      integer(c_int), value :: nsweeps, variant
+      integer(c_int), intent(out) :: result_in_alt
+      integer(c_int) :: rc
+    end function
+
     function ndsmk_residual(g, u, rhs, r) bind(c, name="ndsmk_residual") result(rc)
       import :: ndsmk_grid, c_ptr, c_int
       type(ndsmk_grid), intent(in) :: g

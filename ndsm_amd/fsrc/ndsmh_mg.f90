@@ -30,12 +30,12 @@ module ndsmh_mg
   public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
   public :: MG_BUF_U, MG_BUF_RHS, MG_BUF_R
   public :: MG_OP_RELAX, MG_OP_RESIDUAL, MG_OP_RESTRICT, MG_OP_PROLONG, MG_OP_EXACT, MG_OP_RELAX_COLOR, &
-            MG_OP_RELAX_FUSED, MG_OP_RESREST
+            MG_OP_RELAX_FUSED, MG_OP_RESREST, MG_OP_RELAX_RES, MG_OP_RELAX_RES_FUSED
 
   integer, parameter :: MG_BUF_U = 0, MG_BUF_RHS = 1, MG_BUF_R = 2
   integer, parameter :: MG_OP_RELAX = 0, MG_OP_RESIDUAL = 1, MG_OP_RESTRICT = 2, MG_OP_PROLONG = 3, &
                         MG_OP_EXACT = 4, MG_OP_RELAX_COLOR = 5, MG_OP_RELAX_FUSED = 6, &
-                        MG_OP_RESREST = 7
+                        MG_OP_RESREST = 7, MG_OP_RELAX_RES = 8, MG_OP_RELAX_RES_FUSED = 9
 
   integer(c_size_t), parameter :: R8 = 8_c_size_t, I4 = 4_c_size_t
 
@@ -456,6 +456,14 @@ contains
         s%dl(level)%u = s%dl(level)%ualt
         s%dl(level)%ualt = tmp
       end if
+    case (MG_OP_RELAX_RES, MG_OP_RELAX_RES_FUSED)  ! count sweeps, then residual -> scratch (last sweep + residual in one launch)
+      rc = ndsmk_relax_residual(s%lev(level)%g, s%dl(level)%u, s%dl(level)%ualt, rhs_of(s, level), s%r, &
+                                int(count, c_int), merge(0_c_int, 2_c_int, op == MG_OP_RELAX_RES), swapped)
+      if (rc == 0 .and. swapped /= 0) then
+        tmp = s%dl(level)%u
+        s%dl(level)%u = s%dl(level)%ualt
+        s%dl(level)%ualt = tmp
+      end if
     case (MG_OP_RESIDUAL)
       rc = ndsmk_residual(s%lev(level)%g, s%dl(level)%u, rhs_of(s, level), s%r)
     case (MG_OP_RESTRICT)       ! r(level) -> rhs(level+1), u(level+1) = 0
@@ -496,12 +504,12 @@ contains
 
     ! descend: pre-smooth, residual, restrict (fine_to_coarse, :482-560)
     do l = ltop, s%ngrids - 1
-      rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
       if (s%xf(l)%fused_rr .and. .not. (s%slab .and. l == 1) .and. s%allow_fused_rr) then
+        rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
         rc = ndsmk_residual_restrict(s%lev(l)%g, s%xf(l)%x, s%dl(l)%u, s%dl(l)%rhs, s%dl(l + 1)%rhs, s%dl(l + 1)%u)
         if (rc /= 0) return
       else
-        rc = mg_op(s, MG_OP_RESIDUAL, l, 1); if (rc /= 0) return
+        rc = mg_op(s, MG_OP_RELAX_RES, l, s%ms); if (rc /= 0) return
         rc = mg_op(s, MG_OP_RESTRICT, l, 1); if (rc /= 0) return
       end if
     end do

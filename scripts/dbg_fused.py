@@ -18,7 +18,15 @@ for ns in shapes:
         S.upload(1, _lib.BUF_RHS, rhs)
         NSW = int(os.environ.get("NSW", "1"))
         S.upload(1, _lib.BUF_U, u); S.op(_lib.OP_RELAX_COLOR, 1, NSW); a = S.download(1, _lib.BUF_U)
-        S.upload(1, _lib.BUF_U, u); S.op(_lib.OP_RELAX_FUSED, 1, NSW); b = S.download(1, _lib.BUF_U)
+        if os.environ.get("RES"):
+            S.op(_lib.OP_RESIDUAL, 1); ra = S.download(1, _lib.BUF_R)
+            S.upload(1, _lib.BUF_U, u); S.upload(1, _lib.BUF_R, np.full(shp, np.nan))
+            S.op(_lib.OP_RELAX_RES_FUSED, 1, NSW); b = S.download(1, _lib.BUF_U); rb = S.download(1, _lib.BUF_R)
+            if os.environ.get("RES") == "r":
+                a, b = ra, rb
+                b = np.where(np.isnan(b), 1e300, b)
+        else:
+            S.upload(1, _lib.BUF_U, u); S.op(_lib.OP_RELAX_FUSED, 1, NSW); b = S.download(1, _lib.BUF_U)
         S.close()
         d = np.argwhere(a != b)
         print(ns, bcs, "ndiff", len(d), "of", a.size, "max", np.abs(a - b).max() if len(d) else 0.0)

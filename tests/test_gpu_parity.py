@@ -158,6 +158,34 @@ def test_large_level_kernels_bitwise(hip, port, ns):
     S.close()
 
 
+@pytest.mark.parametrize("ns", ([22, 22, 22], [40, 24, 32], [64, 64, 64], [200, 100, 70], [256, 192, 160]), ids=_tag)
+def test_sweep_plus_residual_launch_bitwise(hip, ns):
+    """the pipeline stage that evaluates r = rhs - L u behind the last sweep (op 9, forced) returns the
+    bits of sweeps-then-residual.hip (which test_kernels3d_bitwise pins to the oracle): every BC set,
+    odd/even sweep counts, general and declared-zero rhs"""
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
+    for bcs in ("NDDNDD", "DNDDND", "DDNDDN", "NNNNND", "DDDDDD"):
+        S = hip.MGSolver(ns, mesh, bcs)
+        for laplace in (False, True):
+            if laplace:
+                S.zero_rhs()
+            else:
+                S.upload(1, hip.BUF_RHS, rhs)
+            for nsw in (1, 2, 5):
+                S.upload(1, hip.BUF_U, u)
+                S.op(hip.OP_RELAX_COLOR, 1, nsw)
+                S.op(hip.OP_RESIDUAL, 1)
+                uw, rw = S.download(1, hip.BUF_U), S.download(1, hip.BUF_R)
+                S.upload(1, hip.BUF_U, u)
+                S.upload(1, hip.BUF_R, np.full(shp, np.nan))
+                S.op(hip.OP_RELAX_RES_FUSED, 1, nsw)
+                assert np.array_equal(S.download(1, hip.BUF_U), uw), (bcs, laplace, nsw)
+                assert np.array_equal(S.download(1, hip.BUF_R), rw), (bcs, laplace, nsw)
+        S.close()
+
+
 @pytest.mark.parametrize("ns", KERNEL_SHAPES_3D, ids=_tag)
 def test_kernels3d_golden(hip, golden_dir, ns):
     """same kernels against the reference's own outputs (no oracle involved)"""
