@@ -197,52 +197,54 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
   }
 
   // ---- per-slot constants of the z loop (byte offsets into an LDS plane) ----
-  // The loop body is issue bound, not bandwidth bound: with few slots per thread
-  // (HOIST) everything that does not depend on k is computed once and kept in
-  // registers; with many slots it is rematerialised per iteration instead (the
-  // registers are needed for the plane windows).
+  // The loop body is issue bound, not bandwidth bound: everything that does not
+  // depend on k is computed once and kept in registers (NS <= 2 slots per thread).
   struct SC {
-    int lo;      // pair's first element
-    int yl, yh;  // signed row deltas to the y neighbours (mirrored at the physical faces)
-    int go;      // offset of the pair inside a global plane
-    int fl;      // bit 0 in-domain, 1 owned, 2/3 element 0/1 inside the x-y update bounds,
-                 // 4/5 element 0/1 mirrors its outer x neighbour, 6 parity base
-    int r0, r1;  // ring of element 0 / 1: stage t may update it iff ring > t
+    int lo;        // pair's first element
+    int yl, yh;    // signed row deltas to the y neighbours (mirrored at the physical faces; 0 where
+                   // the neighbour row is outside the tile - such rows are never updated)
+    int xlo, xhi;  // outer x neighbour of element 0 / 1 (the pair partner where mirrored; always a
+                   // valid offset, never-updated elements point at themselves)
+    int go;        // offset of the pair inside a global plane
+    int fl;        // bit 0 in-domain, 1 owned, 2/3 element 0/1 inside the x-y update bounds, 6 parity
+                   // base, bits 8-11 / 12-15: how many stages element 0 / 1 may take (0: never updated)
   };
   auto make_sc = [&](int tid_, int s) {
     const SlotT q(tid_, s, x0, y0, nx, ny);
     SC c;
     c.lo = 8 * q.lo;
     c.go = q.i + nx * q.j;
-    c.yl = (q.j == 0) ? 8 * TXH : -8 * TXH;
-    c.yh = (q.j == ny - 1) ? -8 * TXH : 8 * TXH;
-    const bool yin = q.j >= g.lb[1] && q.j <= g.ub[1];
     // rows whose y neighbours fall outside the loaded tile can never be updated: ring 0
     const bool yok = q.lj + (q.j == 0 ? 1 : -1) >= 0 && q.lj + (q.j == ny - 1 ? -1 : 1) < TYH;
-    int fl = (q.in ? 1 : 0) | (q.own ? 2 : 0);
-    fl |= (yin && q.i >= g.lb[0] && q.i <= g.ub[0]) ? 4 : 0;
-    fl |= (yin && q.i + 1 >= g.lb[0] && q.i + 1 <= g.ub[0]) ? 8 : 0;
-    fl |= (q.i == 0) ? 16 : 0;
-    fl |= (q.i + 1 == nx - 1) ? 32 : 0;
-    fl |= ((q.i + q.j + g.k0 + fp) & 1) ? 64 : 0;
-    c.fl = fl;
+    c.yl = !yok ? 0 : ((q.j == 0) ? 8 * TXH : -8 * TXH);
+    c.yh = !yok ? 0 : ((q.j == ny - 1) ? -8 * TXH : 8 * TXH);
+    const bool yin = q.j >= g.lb[1] && q.j <= g.ub[1];
+    const bool in0 = yin && q.i >= g.lb[0] && q.i <= g.ub[0];
+    const bool in1 = yin && q.i + 1 >= g.lb[0] && q.i + 1 <= g.ub[0];
+    const bool mir0 = q.i == 0, mir1 = q.i + 1 == nx - 1;
     const int ry = min(openyl ? q.lj : BIG, openyh ? TYH - 1 - q.lj : BIG);
     int r0 = min(min(openxl ? q.li : BIG, openxh ? TXH - 1 - q.li : BIG), ry);
     int r1 = min(min(openxl ? q.li + 1 : BIG, openxh ? TXH - 2 - q.li : BIG), ry);
     // the outer x neighbour must be in the tile unless it is mirrored
-    if (!(fl & 16) && q.li - 1 < 0) r0 = 0;
-    if (!(fl & 32) && q.li + 2 >= TXH) r1 = 0;
-    if (!yok) r0 = r1 = 0;
-    c.r0 = r0;
-    c.r1 = r1;
+    if (!mir0 && q.li - 1 < 0) r0 = 0;
+    if (!mir1 && q.li + 2 >= TXH) r1 = 0;
+    if (!yok || !q.in) r0 = r1 = 0;
+    if (!in0) r0 = 0;
+    if (!in1) r1 = 0;
+    c.xlo = mir0 ? c.lo + 8 : (q.li - 1 >= 0 ? c.lo - 8 : c.lo);
+    c.xhi = mir1 ? c.lo : (q.li + 2 < TXH ? c.lo + 16 : c.lo + 8);
+    int fl = (q.in ? 1 : 0) | (q.own ? 2 : 0) | (in0 ? 4 : 0) | (in1 ? 8 : 0);
+    fl |= ((q.i + q.j + g.k0 + fp) & 1) ? 64 : 0;
+    fl |= min(r0, 15) << 8;
+    fl |= min(r1, 15) << 12;
+    c.fl = fl;
     return c;
   };
-  constexpr bool HOIST = NS <= 2;
-  SC scs[HOIST ? NS : 1];
-  if (HOIST) {
+  static_assert(NS <= 2, "tile / thread-count combinations with more than two pairs per thread are not built");
+  static_assert(NSTG <= 15, "stage budget field is 4 bits");
+  SC scs[NS];
 #pragma unroll
-    for (int s = 0; s < (HOIST ? NS : 1); ++s) scs[s] = make_sc(tid, s);
-  }
+  for (int s = 0; s < NS; ++s) scs[s] = make_sc(tid, s);
   char *const ldsb = reinterpret_cast<char *>(lds);
 #define LDSD(off) (*reinterpret_cast<double *>(ldsb + (off)))
 
@@ -281,70 +283,77 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       }
       return b * (PLANE * 8);
     };
-    // !HOIST: make the thread index opaque once per iteration so that the slot
-    // constants are recomputed here instead of being kept live across the loop
-    int tidk = tid0;
-    if (!HOIST) asm volatile("" : "+v"(tidk));
     // request plane k+2 of u and plane k+1 of rhs before touching plane k
     if (k + 2 <= ke) {
       const double *pk = u + sz * (size_t)(k + 2);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const SC c = HOIST ? scs[HOIST ? s : 0] : make_sc(tidk, s);
-        if (c.fl & 1) nn[s] = ld2(pk + c.go);
-      }
+      for (int s = 0; s < NS; ++s)
+        if (scs[s].fl & 1) nn[s] = ld2(pk + scs[s].go);
     }
     if (!RHS0 && k + 1 <= ke) {
       const double *pk = rhs + sz * (size_t)(k + 1);
 #pragma unroll
-      for (int s = 0; s < (RHS0 ? 1 : NS); ++s) {
-        const SC c = HOIST ? scs[HOIST ? s : 0] : make_sc(tidk, s);
-        if (c.fl & 1) rn[s] = ld2(pk + c.go);
+      for (int s = 0; s < (RHS0 ? 1 : NS); ++s)
+        if (scs[s].fl & 1) rn[s] = ld2(pk + scs[s].go);
+    }
+
+    // ---- this iteration's element of every pair (the same for all stages) ----
+    int ee[NS], eB[NS], oB[NS], xB[NS], lim[NS];
+    double zplus[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const SC c = scs[s];
+      const int e = ((c.fl >> 6) + k) & 1;
+      ee[s] = e;
+      eB[s] = c.lo + 8 * e;      // the element, its pair partner, its outer x neighbour
+      oB[s] = c.lo + 8 - 8 * e;
+      xB[s] = e ? c.xhi : c.xlo;
+      lim[s] = (c.fl >> (8 + 4 * e)) & 15;  // stage t may update it iff lim > t
+      zplus[s] = pick(nxt[s], e);           // plane k+1, untouched by any stage yet
+    }
+
+    // ---- the stages, both slots side by side: loads, arithmetic, write-back ----
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+      const int p = k - t;  // plane of this stage
+      // stage t covers planes [zs-(NSTG-1-t), ze-1+(NSTG-1-t)] of the chunk (uniform test)
+      const bool act = p >= max(zs - (NSTG - 1 - t), 0) && p <= min(ze - 1 + (NSTG - 1 - t), nz - 1);
+      if (!act) continue;
+      const int bB = bufoff(t);
+      const int bZ = bufoff(t + 1);
+      const bool pin = p >= g.lb[2] && p <= g.ub[2];
+      const int pg = p + g.k0;
+      double cur[NS], oth[NS], xn[NS], yhv[NS], ylv[NS], zm[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        cur[s] = LDSD(bB + eB[s]);
+        oth[s] = LDSD(bB + oB[s]);
+        xn[s] = LDSD(bB + xB[s]);
+        yhv[s] = LDSD(bB + eB[s] + scs[s].yh);
+        ylv[s] = LDSD(bB + eB[s] + scs[s].yl);
+        // plane p-1: its LDS copy, or (last stage) the saved final element
+        zm[s] = (t < NSTG - 1) ? LDSD(bZ + eB[s]) : mLe[RES ? 0 : s];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const double xs = oth[s] + xn[s];  // u(xh) + u(xl)
+        const double ys = yhv[s] + ylv[s];
+        const double zhv = (pg == g.nzg - 1) ? zm[s] : zplus[s];
+        const double zlv = (pg == 0) ? zplus[s] : zm[s];
+        const double zsum = zhv + zlv;
+        const double rr = RHS0 ? 0.0 : pick(rw[RHS0 ? 0 : s][RHS0 ? 0 : t], ee[s]);
+        const double unew = xs * g.w[0] + ys * g.w[1] + zsum * g.w[2] - rr;
+        const double nw = g.w1 * unew;
+        const bool upd = pin && lim[s] > t;
+        if (upd) LDSD(bB + eB[s]) = nw;
+        zplus[s] = upd ? nw : cur[s];  // z+1 neighbour of the next stage's plane
       }
     }
 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const SC c = HOIST ? scs[HOIST ? s : 0] : make_sc(tidk, s);
+      const SC c = scs[s];
       const int fl = c.fl;
-      if (!(fl & 1)) continue;
-      // the element every stage of this iteration updates in this pair
-      const int e = ((fl >> 6) + k) & 1;
-      const int eB = c.lo + 8 * e;               // the element, its pair partner, its outer x neighbour
-      const int oB = c.lo + 8 - 8 * e;
-      const int xB = e ? c.lo + 16 : c.lo - 8;
-      const bool xmir = (fl >> (4 + e)) & 1;
-      const bool inb = (fl >> (2 + e)) & 1;
-      const int ring = e ? c.r1 : c.r0;
-      double zplus = pick(nxt[s], e);  // plane k+1, untouched by any stage yet
-
-#pragma unroll
-      for (int t = 0; t < NST; ++t) {
-        const int p = k - t;  // plane of this stage
-        // stage t covers planes [zs-(NST-1-t), ze-1+(NST-1-t)] of the chunk (uniform test)
-        const bool act = p >= max(zs - (NSTG - 1 - t), 0) && p <= min(ze - 1 + (NSTG - 1 - t), nz - 1);
-        if (!act) continue;
-        const int bB = bufoff(t);
-        double cur = LDSD(bB + eB);
-        if (inb && p >= g.lb[2] && p <= g.ub[2] && ring > t) {
-          const int pg = p + g.k0;
-          const double other = LDSD(bB + oB);
-          const double xn = xmir ? other : LDSD(bB + xB);
-          const double xs = (e == 0) ? (other + xn) : (xn + other);  // u(xh) + u(xl)
-          const double ys = LDSD(bB + eB + c.yh) + LDSD(bB + eB + c.yl);
-          // plane p-1: its LDS copy, or (last stage) the saved final element
-          const double zminus = (t < NSTG - 1) ? LDSD(bufoff(t + 1) + eB) : mLe[RES ? 0 : s];
-          const double zhv = (pg == g.nzg - 1) ? zminus : zplus;
-          const double zlv = (pg == 0) ? zplus : zminus;
-          const double zsum = zhv + zlv;
-          const double rr = RHS0 ? 0.0 : pick(rw[RHS0 ? 0 : s][RHS0 ? 0 : t], e);
-          const double unew = xs * g.w[0] + ys * g.w[1] + zsum * g.w[2] - rr;
-          cur = g.w1 * unew;
-          LDSD(bB + eB) = cur;
-        }
-        zplus = cur;  // z+1 neighbour of the next stage's plane
-      }
-
       // plane k-NST+1 has passed its last stage: store it, keep what the next
       // iteration's last stage needs from it (its other element, already final)
       const int pf = k - (NST - 1);
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       if (pf >= ks) {
         fin = ld2(reinterpret_cast<const double *>(ldsb + bufoff(NST - 1) + c.lo));
         if (pf >= zs && pf < ze && (fl & 2)) st2(uout + sz * (size_t)pf + c.go, fin);
-        if (!RES) mLe[RES ? 0 : s] = pick(fin, 1 - e);
+        if (!RES) mLe[RES ? 0 : s] = pick(fin, 1 - ee[s]);
       }
       if (RES) {
         // residual of plane k-NST: centre f1, below f2, above fin (all final)
@@ -361,8 +370,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
         const d2 cc = f1[RES ? s : 0], below = f2[RES ? s : 0];
         if (pr >= zs && pr < ze && (fl & 2)) {
           const int bR = bufoff(NST);
-          const double xl0 = (fl & 16) ? cc.y : LDSD(bR + c.lo - 8);
-          const double xh1 = (fl & 32) ? cc.x : LDSD(bR + c.lo + 16);
+          const double xl0 = LDSD(bR + c.xlo);
+          const double xh1 = LDSD(bR + c.xhi);
           const d2 vl = ld2(reinterpret_cast<const double *>(ldsb + bR + c.lo + c.yl));
           const d2 vh = ld2(reinterpret_cast<const double *>(ldsb + bR + c.lo + c.yh));
           const int prg = pr + g.k0;
@@ -386,13 +395,12 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 
     __syncthreads();  // every stage is done with its plane
 
-    // ---- plane k+1 takes the LDS buffer of plane k-NST+1; shift the windows ----
+    // ---- plane k+1 takes the LDS buffer of plane k-NSTG+1; shift the windows ----
     {
       char *bn = ldsb + bufoff(-1);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const SC c = HOIST ? scs[HOIST ? s : 0] : make_sc(tidk, s);
-        if (k + 1 <= ke && tid0 + NT * s < NPAIR) st2(reinterpret_cast<double *>(bn + c.lo), nxt[s]);
+        if (k + 1 <= ke && tid0 + NT * s < NPAIR) st2(reinterpret_cast<double *>(bn + scs[s].lo), nxt[s]);
         nxt[s] = nn[s];
       }
       if (!RHS0) {
@@ -526,7 +534,6 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
   if (two) {
     switch (cfg[0]) {
       case 3: rc = launch_cfg<2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;
-      case 4: rc = launch_cfg<2, 72, 30, 512, 4>(g, u, uout, rhs, tgt); break;
       case 5: rc = launch_cfg<2, 72, 28, 512, 4>(g, u, uout, rhs, tgt); break;
       default: rc = launch_cfg<2, 136, 30, 1024, 4>(g, u, uout, rhs, tgt); break;
     }
@@ -537,7 +544,6 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
   if (res && max_sweeps == 1) {
     switch (cfg[2]) {
       case 1: rc = (launch_cfg<1, 136, 30, 1024, 4, true>(g, u, uout, rhs, tgt, rout)); break;
-      case 4: rc = (launch_cfg<1, 72, 30, 512, 4, true>(g, u, uout, rhs, tgt, rout)); break;
       default: rc = (launch_cfg<1, 136, 22, 768, 4, true>(g, u, uout, rhs, tgt, rout)); break;
     }
     if (rc) return rc;
@@ -546,10 +552,6 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
     return 0;
   }
   switch (cfg[1] ? cfg[1] : (big ? 7 : 8)) {
-    case 1: rc = launch_cfg<1, 132, 62, 1024, 4>(g, u, uout, rhs, tgt); break;
-    case 2: rc = launch_cfg<1, 68, 30, 256, 4>(g, u, uout, rhs, tgt); break;
-    case 4: rc = launch_cfg<1, 68, 60, 512, 4>(g, u, uout, rhs, tgt); break;
-    case 5: rc = launch_cfg<1, 132, 31, 512, 4>(g, u, uout, rhs, tgt); break;
     case 8: rc = launch_cfg<1, 132, 23, 768, 4>(g, u, uout, rhs, tgt); break;
     default: rc = launch_cfg<1, 132, 31, 1024, 4>(g, u, uout, rhs, tgt); break;
   }
