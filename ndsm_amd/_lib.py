@@ -21,7 +21,8 @@ class NdsmHipError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libndsm_hip.so")
+    # NDSM_HIP_LIB: development override (A/B builds of the same library)
+    return os.environ.get("NDSM_HIP_LIB") or os.path.join(HERE, "lib", "libndsm_hip.so")
 
 
 def load_library(path=None):

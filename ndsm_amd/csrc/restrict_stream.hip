@@ -16,6 +16,7 @@
 // six to three.
 #include "common.hpp"
 
+
 namespace {
 
 struct RSArgs {
@@ -45,7 +46,7 @@ __device__ __forceinline__ void st2(double *p, const d2 a) {
   *reinterpret_cast<double2 *>(p) = t;
 }
 
-template <int CI, int CJ, int MT>
+template <int CI, int CJ, int MT, int KCMAX>
 __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const double *__restrict__ f, double *__restrict__ rhs_c,
                                                             double *__restrict__ u_c, RSArgs a) {
   constexpr int NT = CI * CJ;
@@ -74,37 +75,36 @@ __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const double *__rest
   const int kB = a.rlo[2][Ke - 1] + a.rcnt[2][Ke - 1] - 1;
   const int tid = (int)threadIdx.x;
 
-  // ---- this thread's coarse column and its z-independent weights ----
+  // ---- this thread's coarse column and its x / y tap weights ----
   const int I = I0 + tid % CI, J = J0 + tid / CI;
   const bool chave = I < a.nc[0] && J < a.nc[1];
   int ni = 0, nj = 0, li0 = 0, lj0 = 0;
-  double wxy[MT][MT];
+  double cx[MT], cy[MT];
 #pragma unroll
-  for (int jj = 0; jj < MT; ++jj)
-#pragma unroll
-    for (int ii = 0; ii < MT; ++ii) wxy[jj][ii] = 0.0;
+  for (int q = 0; q < MT; ++q) cx[q] = cy[q] = 0.0;
   if (chave) {
     ni = a.rcnt[0][I];
     nj = a.rcnt[1][J];
     li0 = a.rlo[0][I] - fx0;
     lj0 = a.rlo[1][J] - fy0;
 #pragma unroll
-    for (int jj = 0; jj < MT; ++jj) {
-      const double c2y = jj < nj ? a.rw[1][(size_t)J * a.maxt[1] + jj] : 0.0;
-#pragma unroll
-      for (int ii = 0; ii < MT; ++ii) {
-        const double c2x = ii < ni ? a.rw[0][(size_t)I * a.maxt[0] + ii] : 0.0;
-        double wv = c2x * a.w2[0];  // 1 * c2 * w2 (ndsm_interp.f90:277-282)
-        wv = wv * c2y * a.w2[1];
-        wxy[jj][ii] = wv;
-      }
+    for (int q = 0; q < MT; ++q) {
+      cx[q] = q < ni ? a.rw[0][(size_t)I * a.maxt[0] + q] : 0.0;
+      cy[q] = q < nj ? a.rw[1][(size_t)J * a.maxt[1] + q] : 0.0;
     }
   }
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;  // coarse planes K with K & 3 = 0..3
-  int Klo = Ks;
+  // z tables of this chunk's coarse planes in LDS: the plane loop reads them at uniform
+  // addresses (from global memory every lookup is a dependent ~1 us load in the inner loop)
+  __shared__ int s_z0[KCMAX], s_nk[KCMAX];
+  __shared__ double s_zw[KCMAX * MT];
+  for (int t = tid; t < Ke - Ks; t += NT) {
+    const int nk = a.rcnt[2][Ks + t];
+    s_z0[t] = a.rlo[2][Ks + t];
+    s_nk[t] = nk;
+    for (int q = 0; q < MT; ++q) s_zw[t * MT + q] = q < nk ? a.rw[2][(size_t)(Ks + t) * a.maxt[2] + q] : 0.0;
+  }
 
-  d2 nxt[NS], nn[NS];
-#define RS_LOAD(kglob, dst)                                                              \
+#define RS_LOAD(tid, kglob, dst)                                                            \
   do {                                                                                   \
     const int kl_ = (kglob) - a.f_k0; /* local fine plane */                             \
     _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {                                  \
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const double *__rest
       dst[s_] = t_;                                                                      \
     }                                                                                    \
   } while (0)
-#define RS_STORE(buf, src)                                                               \
+#define RS_STORE(tid, buf, src)                                                               \
   do {                                                                                   \
     _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {                                  \
       const int p_ = tid + NT * s_;                                                      \
@@ -127,62 +127,121 @@ __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const double *__rest
     }                                                                                    \
   } while (0)
 
-  RS_LOAD(kA, nxt);
-  RS_STORE(lds, nxt);
-  RS_LOAD(kA + 1, nxt);
-  __syncthreads();
+  // cxw = c2x w2x: first factor of the weight chain ((((c2x w2x) c2y) w2y) c2z) w2z
+  double cxw[MT];
+#pragma unroll
+  for (int q = 0; q < MT; ++q) cxw[q] = cx[q] * a.w2[0];  // 1 * c2 * w2 (ndsm_interp.f90:277-282)
+  // a wave is one row of coarse columns (CI = 64 lanes, one J): the y tap count is wave-uniform
+  const int njw = __builtin_amdgcn_readfirstlane(nj);
+
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;  // coarse planes K with K & 3 = 0..3
+  int Klo = Ks;
+  auto getacc = [&](int slot) { return slot == 0 ? acc0 : (slot == 1 ? acc1 : (slot == 2 ? acc2 : acc3)); };
+  // a coarse plane's sum after this fine plane: store it when its window is complete
+  auto finish = [&](int K, double fc, bool complete) {
+    if (complete) {
+      if (chave) {
+        const size_t c = (size_t)I + (size_t)a.nc[0] * ((size_t)J + (size_t)a.nc[1] * (size_t)(K - a.c_k0));
+        rhs_c[c] = fc;
+        if (u_c) u_c[c] = 0.0;  // ndsm_multigrid_core.f90:557-558
+      }
+      fc = 0.0;
+    }
+    const int slot = K & 3;
+    acc0 = slot == 0 ? fc : acc0;
+    acc1 = slot == 1 ? fc : acc1;
+    acc2 = slot == 2 ? fc : acc2;
+    acc3 = slot == 3 ? fc : acc3;
+  };
+
+  d2 nxt[NS];
+  RS_LOAD(tid, kA, nxt);
+  RS_STORE(tid, lds, nxt);
+  __syncthreads();  // also publishes the z tables
 
   for (int k = kA; k <= kB; ++k) {
     const double *R = lds + ((k - kA) & 1) * PLANE;
-    RS_LOAD(k + 2, nn);
+    // the staging geometry is cheap integer work: rebuilt per plane from an opaque copy of the
+    // thread index instead of being kept live across the tap loops
+    int tidk = tid;
+    asm volatile("" : "+v"(tidk));
+    RS_LOAD(tidk, k + 1, nxt);  // in flight while plane k is consumed
 
-    if (chave) {
-      for (int K = Klo; K < Ke; ++K) {
-        const int z0 = a.rlo[2][K];
-        if (z0 > k) break;
-        const int nk = a.rcnt[2][K];
-        if (k >= z0 + nk) continue;
-        const double c2z = a.rw[2][(size_t)K * a.maxt[2] + (k - z0)];
-        const int slot = K & 3;
-        double fc = slot == 0 ? acc0 : (slot == 1 ? acc1 : (slot == 2 ? acc2 : acc3));
+    // Every thread walks the same coarse planes (threads without a coarse column have no taps
+    // and store nothing), so the loop control stays scalar.  A fine plane usually feeds two
+    // coarse planes: their accumulation chains - serial, the (z, y, x) tap order is part of the
+    // result - are interleaved so that each hides the other's latency, and every patch value
+    // read from LDS and every x-y weight prefix serves both.
+    const double *P = R + li0 + FX * lj0;  // first tap of this column in the plane
+    int K = Klo;
+    while (K < Ke) {
+      const int z0 = __builtin_amdgcn_readfirstlane(s_z0[K - Ks]);
+      if (z0 > k) break;
+      const int nk = __builtin_amdgcn_readfirstlane(s_nk[K - Ks]);
+      if (k >= z0 + nk) {
+        ++K;
+        continue;
+      }
+      int z1 = 0, nk1 = 0;
+      bool two = false;
+      if (K + 1 < Ke) {
+        z1 = __builtin_amdgcn_readfirstlane(s_z0[K + 1 - Ks]);
+        nk1 = __builtin_amdgcn_readfirstlane(s_nk[K + 1 - Ks]);
+        two = z1 <= k && k < z1 + nk1;
+      }
+      const double c2za = s_zw[(K - Ks) * MT + (k - z0)];
+      double fa = getacc(K & 3);
+      if (two) {
+        const double c2zb = s_zw[(K + 1 - Ks) * MT + (k - z1)];
+        double fb = getacc((K + 1) & 3);
 #pragma unroll
         for (int jj = 0; jj < MT; ++jj) {
-          if (jj < nj) {
-            const double *row = R + li0 + FX * (lj0 + jj);
+          if (jj < njw) {
 #pragma unroll
             for (int ii = 0; ii < MT; ++ii) {
               if (ii < ni) {
-                const double wv = wxy[jj][ii] * c2z * a.w2[2];
-                fc = fc + wv * row[ii];
+                const double w0 = cxw[ii] * cy[jj] * a.w2[1];
+                const double wa = w0 * c2za * a.w2[2];
+                const double wb = w0 * c2zb * a.w2[2];
+                const double fv = P[ii + FX * jj];
+                fa = fa + wa * fv;
+                fb = fb + wb * fv;
               }
             }
           }
         }
-        if (k == z0 + nk - 1) {  // window complete: the coarse value is final
-          const size_t c = (size_t)I + (size_t)a.nc[0] * ((size_t)J + (size_t)a.nc[1] * (size_t)(K - a.c_k0));
-          rhs_c[c] = fc;
-          if (u_c) u_c[c] = 0.0;  // ndsm_multigrid_core.f90:557-558
-          fc = 0.0;
+        finish(K, fa, k == z0 + nk - 1);
+        finish(K + 1, fb, k == z1 + nk1 - 1);
+        K += 2;
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < MT; ++jj) {
+          if (jj < njw) {
+#pragma unroll
+            for (int ii = 0; ii < MT; ++ii) {
+              if (ii < ni) {
+                const double w0 = cxw[ii] * cy[jj] * a.w2[1];
+                const double wa = w0 * c2za * a.w2[2];
+                fa = fa + wa * P[ii + FX * jj];
+              }
+            }
+          }
         }
-        acc0 = slot == 0 ? fc : acc0;
-        acc1 = slot == 1 ? fc : acc1;
-        acc2 = slot == 2 ? fc : acc2;
-        acc3 = slot == 3 ? fc : acc3;
+        finish(K, fa, k == z0 + nk - 1);
+        K += 1;
       }
-      while (Klo < Ke && a.rlo[2][Klo] + a.rcnt[2][Klo] - 1 <= k) ++Klo;
     }
+    while (Klo < Ke && __builtin_amdgcn_readfirstlane(s_z0[Klo - Ks] + s_nk[Klo - Ks]) - 1 <= k) ++Klo;
 
     // plane k+1 into the other buffer (its readers finished one barrier ago)
-    RS_STORE(lds + ((k + 1 - kA) & 1) * PLANE, nxt);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) nxt[s] = nn[s];
+    RS_STORE(tidk, lds + ((k + 1 - kA) & 1) * PLANE, nxt);
     __syncthreads();
   }
 #undef RS_LOAD
 #undef RS_STORE
 }
 
-constexpr int kCI = 64, kCJ = 16, kMT = 5;
+constexpr int kCI = 64, kCJ = 16, kMT = 5, kKCMax = 64;
 
 }  // namespace
 
@@ -215,16 +274,30 @@ int launch_restrict_stream(const ndsmk_xfer *x, const double *r_f, double *rhs_c
   a.nti = (x->nc[0] + kCI - 1) / kCI;
   a.ntj = (x->nc[1] + kCJ - 1) / kCJ;
   const int tiles = a.nti * a.ntj;
-  int nkc = (768 + tiles - 1) / tiles;
-  if (nkc < 1) nkc = 1;
-  int kc = (x->c_cnt + nkc - 1) / nkc;
-  if (kc < 8) kc = 8 < x->c_cnt ? 8 : x->c_cnt;
+  // coarse planes per chunk: one workgroup per CU at a time (LDS), a chunk of kc coarse planes
+  // walks ~2 kc + 3 fine planes: minimise (rounds of workgroups) x (planes walked); the chunk's
+  // z tables must fit their LDS arrays (kc <= kKCMax)
+  const int64_t slots = ndsm::cu_count();
+  int kc = x->c_cnt < kKCMax ? x->c_cnt : kKCMax;
+  int64_t best = -1;
+  for (int c = 1; c <= x->c_cnt; ++c) {
+    const int k1 = (x->c_cnt + c - 1) / c;
+    if (k1 > kKCMax) continue;
+    const int c1 = (x->c_cnt + k1 - 1) / k1;
+    const int64_t rounds = ((int64_t)tiles * c1 + slots - 1) / slots;
+    const int64_t cost = rounds * (2 * k1 + 3);
+    if (best < 0 || cost < best) {
+      best = cost;
+      kc = k1;
+    }
+    if (k1 <= 4) break;
+  }
   a.kc = kc;
   a.nkc = (x->c_cnt + kc - 1) / kc;
   a.nwork = tiles * a.nkc;
   const int nblk = ((a.nwork + 7) / 8) * 8;
   constexpr size_t lds_bytes = sizeof(double) * 2 * (2 * kCI + 6) * (2 * kCJ + 5);
-  auto kfn = restrict_stream_k<kCI, kCJ, kMT>;
+  auto kfn = restrict_stream_k<kCI, kCJ, kMT, kKCMax>;
   static bool attr_set = false;
   if (!attr_set) {
     NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
