@@ -527,10 +527,14 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
   const int *cfg = fused_cfg();
   const int tgt = cfg[3] > 0 ? cfg[3] : 0;  // > 0: that many work items instead of launch_cfg's own choice
   const bool big = npts >= (int64_t)64 * 1024 * 1024;
-  const bool res = rout && res_done && !slab && cfg[2] != 9;
-  // two sweeps per pass - not for slabs (2 ghost planes are exchanged per sweep), and not
-  // for the last two sweeps when the residual is wanted (it rides on a one-sweep pass)
-  const bool two = max_sweeps >= 2 && !slab && cfg[0] != 9 && !(res && max_sweeps == 2);
+  // A z-slab carries zown0 ghost planes below and n[2] - zown1 above its owned range; the caller
+  // (ndsmh_world) has exchanged as many as the pass it asks for consumes: 2 per sweep, +1 for
+  // the residual stage.
+  const int ghosts = slab ? (g.zown0 < g.n[2] - g.zown1 ? g.zown0 : g.n[2] - g.zown1) : 1 << 20;
+  const bool res = rout && res_done && ghosts >= 3 && cfg[2] != 9;
+  // two sweeps per pass - not for the last two sweeps when the residual is wanted (it rides
+  // on a one-sweep pass)
+  const bool two = max_sweeps >= 2 && ghosts >= 4 && cfg[0] != 9 && !(res && max_sweeps == 2);
   if (two) {
     switch (cfg[0]) {
       case 3: rc = launch_cfg<2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;

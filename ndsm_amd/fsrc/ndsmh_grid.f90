@@ -92,7 +92,7 @@ contains
       plan(r)%z1 = int((int(r + 1, ik) * nz) / nranks)
       plan(r)%ck0 = nzc; plan(r)%ck1 = 0
     end do
-    depth = 2
+    depth = 4      ! two sweeps per halo exchange: each sweep consumes two ghost planes per side
     do kc = 0, nzc - 1
       lo = tz%rlo(kc + 1); hi = lo + tz%rcnt(kc + 1)      ! fine taps [lo, hi)
       m = lo + tz%rcnt(kc + 1) / 2

@@ -86,7 +86,7 @@ module ndsmh_world
     logical :: rccl = .false.
     type(mg_solver), allocatable :: loc(:)
     type(slab_t), allocatable :: plan(:)     ! (0:nranks-1), identical on every rank
-    logical :: ghosts_ok = .false.   ! ghost planes of u(1) match the neighbours' owned planes
+    integer :: ghost_depth = 0       ! this many ghost planes of u(1) per side match the neighbours' owned planes
     integer(ik) :: nzg = 0
   end type
 
@@ -141,7 +141,7 @@ contains
       rc = mg_create(w%loc(i), 3, nshape, qx, qy, qz, bcs, ngrids_req, w%plan(w%first + i - 1))
       if (rc /= 0) return
     end do
-    w%ghosts_ok = .false.
+    w%ghost_depth = 0
     rc = 0
   end function
 
@@ -183,7 +183,7 @@ contains
                      dptr_offset(host, int(a - gz0, c_size_t) * int(s%plane1, c_size_t) * R8), &
                      int(b - a, c_size_t) * int(s%plane1, c_size_t) * R8)
     end associate
-    if (which == MG_BUF_U) w%ghosts_ok = .false.
+    if (which == MG_BUF_U) w%ghost_depth = 0
     if (which == MG_BUF_RHS) call mg_mark_rhs_set(w%loc(ilocal))
   end function
 
@@ -350,22 +350,49 @@ contains
     if (w%rccl) rc = ndsmk_dist_group_end()
   end function
 
-  ! nsweeps x { make the ghosts current ; one fused sweep of every local slab }
-  function world_relax(w, nsweeps) result(rc)
+  ! make at least `depth` ghost planes of u(1) per side current
+  function need_ghosts(w, depth) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: depth
+    integer(c_int) :: rc
+    rc = 0
+    if (w%ghost_depth >= depth) return
+    rc = exchange(w, MG_BUF_U, depth); if (rc /= 0) return
+    w%ghost_depth = depth
+  end function
+
+  ! nsweeps sweeps of every local slab.  A sweep consumes two ghost planes per side (red needs
+  ! black of the neighbour plane, black needs that red), so a halo exchange of depth 4 feeds a
+  ! two-sweep pass of the temporally blocked kernel: half the messages, half the passes over HBM.
+  ! with_res: the residual rides on the last sweep (depth 3: one more plane for its stencil).
+  function world_relax(w, nsweeps, with_res) result(rc)
     type(mg_world), intent(inout) :: w
     integer, intent(in) :: nsweeps
+    logical, intent(in), optional :: with_res
     integer(c_int) :: rc
-    integer :: sw, i
+    integer :: left, n, i
+    logical :: res, two_ok
     rc = 0
-    do sw = 1, nsweeps
-      if (.not. w%ghosts_ok) then
-        rc = exchange(w, MG_BUF_U, 2); if (rc /= 0) return
-        w%ghosts_ok = .true.
+    res = .false.
+    if (present(with_res)) res = with_res
+    two_ok = w%plan(0)%g >= 4
+    left = nsweeps
+    do while (left > 0)
+      n = 1
+      if (two_ok .and. left >= 2 .and. .not. (res .and. left == 2)) n = 2
+      if (res .and. left == 1) then
+        rc = need_ghosts(w, 3); if (rc /= 0) return
+        do i = 1, w%nlocal
+          rc = mg_op(w%loc(i), MG_OP_RELAX_RES_FUSED, 1, 1); if (rc /= 0) return
+        end do
+      else
+        rc = need_ghosts(w, 2 * n); if (rc /= 0) return
+        do i = 1, w%nlocal
+          rc = mg_op(w%loc(i), MG_OP_RELAX_FUSED, 1, n); if (rc /= 0) return
+        end do
       end if
-      do i = 1, w%nlocal
-        rc = mg_op(w%loc(i), MG_OP_RELAX_FUSED, 1, 1); if (rc /= 0) return
-      end do
-      w%ghosts_ok = .false.
+      w%ghost_depth = 0
+      left = left - n
     end do
   end function
 
@@ -375,14 +402,15 @@ contains
     integer :: i
 
     ! ---- level 1, downwards (fine_to_coarse, ndsm_multigrid_core.f90:482-560)
-    rc = world_relax(w, w%loc(1)%ms); if (rc /= 0) return
-    if (.not. w%ghosts_ok) then         ! the residual reads one ghost plane of u
-      rc = exchange(w, MG_BUF_U, 2); if (rc /= 0) return
-      w%ghosts_ok = .true.
+    if (w%loc(1)%ms >= 1 .and. w%plan(0)%g >= 3) then
+      rc = world_relax(w, w%loc(1)%ms, .true.); if (rc /= 0) return
+    else
+      rc = world_relax(w, w%loc(1)%ms); if (rc /= 0) return
+      rc = need_ghosts(w, 2); if (rc /= 0) return   ! the residual reads one ghost plane of u
+      do i = 1, w%nlocal
+        rc = mg_op(w%loc(i), MG_OP_RESIDUAL, 1, 1); if (rc /= 0) return
+      end do
     end if
-    do i = 1, w%nlocal
-      rc = mg_op(w%loc(i), MG_OP_RESIDUAL, 1, 1); if (rc /= 0) return
-    end do
     rc = exchange(w, MG_BUF_R, w%plan(0)%g); if (rc /= 0) return
     do i = 1, w%nlocal
       rc = mg_slab_restrict(w%loc(i)); if (rc /= 0) return
@@ -405,7 +433,7 @@ contains
     do i = 1, w%nlocal
       rc = mg_slab_prolong(w%loc(i)); if (rc /= 0) return
     end do
-    w%ghosts_ok = .false.
+    w%ghost_depth = 0
     rc = world_relax(w, w%loc(1)%ms)
   end function
 
