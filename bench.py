@@ -189,7 +189,8 @@ def main():
                 raise RuntimeError(rccl_err)
             S = _lib.World(n3, mesh, "NDDNDD", world, rank, ms=ms, lib=L)
             _m, win, a = slab_window_problem(n3, S.slabs[0])
-            S.upload_window(1, _lib.BUF_U, win, a)                # rhs stays zero (Laplace)
+            S.upload_window(1, _lib.BUF_U, win, a)
+            S.zero_rhs()                                          # Laplace problem, as on one GPU
             del win
             S.vcycle(1)
             S.sync()
@@ -204,8 +205,8 @@ def main():
             ngrids = 8
             workload = (f"1024x1024x512 Poisson (Ax boundary data), one V-cycle per step (ms={ms}), "
                         "config[3] of BASELINE.json")
-            parallelism = (f"level 1 in {world} z-slabs (RCCL send/recv halo, 2 planes per neighbour per sweep), "
-                           "levels>=2 on rank 0")
+            parallelism = (f"level 1 in {world} z-slabs (RCCL send/recv halo: 4 planes per neighbour per two-sweep "
+                           "pass), levels>=2 on rank 0")
             scaling = "strong"
             slab_mode = True
         else:

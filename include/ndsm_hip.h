@@ -121,6 +121,54 @@ int ndsm_hip_mg_solve(void *handle, double vc_tol, int nmax, double *du_last, in
                       double *hist, int hist_len);
 int ndsm_hip_mg_info(void *handle, int64_t *exact_sweeps, int64_t *unconverged_coarse_solves);
 
+/* =====================================================================
+ * PART 3 - additive exports, multi-GPU
+ *
+ * One process per GPU.  Level 1 is cut into z-slabs, one per rank; every slab
+ * carries `g` ghost planes per side; neighbours exchange 4 planes per two-sweep
+ * pass over RCCL (ncclSend / ncclRecv on the library stream); the restricted
+ * residual is gathered to rank 0, which runs levels >= 2 and scatters the coarse
+ * correction back.  Results are bit-identical to the single-GPU solver (tests:
+ * loop-back world on one GPU, 2-rank gloo model on the CPU).
+ * ===================================================================== */
+
+/* RCCL bootstrap: rank 0 fills id128 (128 bytes), the caller broadcasts it by its own means
+ * (MPI, torch.distributed/gloo, a file), every rank then calls dist_init.  Requires
+ * ndsm_hip_init(local device) first. */
+int ndsm_hip_dist_unique_id(void *id128);
+int ndsm_hip_dist_init(int rank, int nranks, const void *id128);
+
+/* Slab plan for nranks ranks, 12 ints per rank: rank, z0, z1 (owned fine planes), g (ghost
+ * depth), nloc (= z1 - z0 + 2 g), k0 (global index of local plane 0), ck0, ck1 (coarse planes it
+ * restricts), pk0, pk1 (coarse planes it needs for prolongation), cb0, cb1 (coarse buffer window).
+ * Pure host arithmetic (no GPU needed).  Returns 0, or 9002 when the shape cannot be cut that way. */
+int ndsm_hip_slab_plan(const int *nshape, const double *x, const double *y, const double *z, int ngrids,
+                       int nranks, int *out /* [nranks][12] */);
+
+/* rank >= 0: this process holds slab `rank` (RCCL transport, after ndsm_hip_dist_init);
+ * rank <  0: loop-back world - all nranks slabs on this GPU, neighbours reached by device copies
+ *            (verification of the slab algebra on one GPU). */
+int ndsm_hip_world_create(const int *nshape, const double *x, const double *y, const double *z,
+                          const char *bcs, int ngrids, int ms, double ex_tol, int du_max, int nmax_exact,
+                          int nranks, int rank, void **handle);
+int ndsm_hip_world_destroy(void *handle);
+int ndsm_hip_world_nlocal(void *handle);                          /* slabs held by this process */
+int ndsm_hip_world_slab(void *handle, int ilocal, int *info12);   /* its plan row */
+/* which: 0 = u, 1 = rhs, 2 = residual.  host holds nplanes whole x-y planes starting at GLOBAL
+ * plane gz0; the planes that fall into slab ilocal's window (ghosts included) are copied. */
+int ndsm_hip_world_upload(void *handle, int ilocal, int which, const double *host, int gz0, int nplanes);
+int ndsm_hip_world_download(void *handle, int ilocal, int which, double *host /* owned planes */);
+int ndsm_hip_world_zero_rhs(void *handle);                        /* as ndsm_hip_mg_zero_rhs */
+int ndsm_hip_world_relax(void *handle, int nsweeps);              /* collective */
+int ndsm_hip_world_vcycle(void *handle, int ncycles);             /* collective, asynchronous */
+/* collective; every rank returns the same history.  0 converged, 1 not, >= 9001 error */
+int ndsm_hip_world_solve(void *handle, double vc_tol, int nmax, double *du_last, int *ncycles, double *hist,
+                         int hist_len);
+
+/* "hip=<path>;rccl=<path>": the shared objects this library's HIP / RCCL calls are bound to
+ * (a process that also imports PyTorch holds two ROCm stacks) */
+int ndsm_hip_bound_libs(char *buf, int len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ def load_library(path=None):
     L.ndsm_hip_world_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int]
     L.ndsm_hip_world_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
     L.ndsm_hip_world_relax.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.ndsm_hip_world_zero_rhs.argtypes = [ctypes.c_void_p]
     L.ndsm_hip_world_vcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndsm_hip_world_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, _dp, _ip, _dp, ctypes.c_int]
     if path is None:
@@ -80,7 +81,7 @@ def bound_libs(L=None):
     """paths of the HIP and RCCL shared objects our calls are bound to"""
     L = L or load_library()
     buf = ctypes.create_string_buffer(1024)
-    L.ndsmk_bound_libs(buf, 1024)
+    L.ndsm_hip_bound_libs(buf, 1024)
     return dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
 
 
@@ -271,6 +272,10 @@ class World:
 
     def relax(self, n=1):
         _check(self.L.ndsm_hip_world_relax(self.h, n), "world_relax", self.L)
+
+    def zero_rhs(self):
+        """Declare rhs == 0 on level 1 (Laplace problem): the kernels stop reading it; same bits."""
+        _check(self.L.ndsm_hip_world_zero_rhs(self.h), "world_zero_rhs", self.L)
 
     def vcycle(self, n=1):
         _check(self.L.ndsm_hip_world_vcycle(self.h, n), "world_vcycle", self.L)

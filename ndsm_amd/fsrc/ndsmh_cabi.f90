@@ -621,6 +621,33 @@ contains
     rc = world_relax(w, int(nsweeps))
   end function
 
+  function ndsm_hip_world_zero_rhs(handle) bind(c, name="ndsm_hip_world_zero_rhs") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int) :: rc
+    type(mg_world), pointer :: w
+    integer :: i
+    call c_f_pointer(handle, w)
+    rc = 0
+    do i = 1, w%nlocal
+      rc = mg_zero_rhs(w%loc(i)); if (rc /= 0) return
+    end do
+  end function
+
+  function ndsm_hip_bound_libs(buf, len) bind(c, name="ndsm_hip_bound_libs") result(rc)
+    type(c_ptr), value :: buf
+    integer(c_int), value :: len
+    integer(c_int) :: rc
+    interface
+      function ndsmk_bound_libs(buf, len) bind(c, name="ndsmk_bound_libs") result(rc)
+        import :: c_ptr, c_int
+        type(c_ptr), value :: buf
+        integer(c_int), value :: len
+        integer(c_int) :: rc
+      end function
+    end interface
+    rc = ndsmk_bound_libs(buf, len)
+  end function
+
   function ndsm_hip_world_vcycle(handle, ncycles) bind(c, name="ndsm_hip_world_vcycle") result(rc)
     type(c_ptr), value :: handle
     integer(c_int), value :: ncycles
