@@ -79,6 +79,10 @@ int get_iopt_ngrids(void);   /* -> 9  in : cap on the number of grid levels, 0 =
                                           floor(log2(nmin/2)) (ndsm_vector_potential.f90:631-632) */
 int get_iopt_ncyc_out(void); /* -> 10 out: V-cycles used by the last solve that iterated */
 int get_ropt_dulast(void);   /* -> 3  out: du of its last V-cycle */
+int get_iopt_prec(void);     /* -> 11 in : 0 fp64 throughout (reference arithmetic); 1 mixed precision for the 3-D
+                                          solves: fp64 residual + fp32 correction V-cycle on level 1 (BASELINE
+                                          config[4]); where level 1 is too small for the fp32 kernels the
+                                          fp64 path runs */
 
 int ndsm_hip_device_count(void);
 int ndsm_hip_init(int device);               /* < 0: LOCAL_RANK % device count; idempotent */
@@ -105,6 +109,9 @@ int ndsm_hip_mg_create(int ndim, const int *nshape, const double *x, const doubl
 int ndsm_hip_mg_destroy(void *handle);
 int ndsm_hip_mg_levels(void *handle, int ngrids_cap, int *shapes /* [ngrids_cap][3] */); /* returns ngrids */
 int ndsm_hip_mg_set_ms(void *handle, int ms);
+/* mode 0 fp64, 1 mixed where level 1 is large (>= 6 M points), 2 mixed wherever the fp32 kernels cover
+ * level 1.  Returns 1 if ndsm_hip_mg_solve will run in mixed precision, 0 if fp64, < 0 bad mode. */
+int ndsm_hip_mg_set_precision(void *handle, int mode);
 /* which: 0 = u, 1 = rhs, 2 = residual scratch (level-1 sized) */
 int ndsm_hip_mg_upload(void *handle, int level, int which, const double *host);
 int ndsm_hip_mg_download(void *handle, int level, int which, double *host);

@@ -48,6 +48,7 @@ def load_library(path=None):
     L.ndsm_hip_mg_destroy.argtypes = [ctypes.c_void_p]
     L.ndsm_hip_mg_levels.argtypes = [ctypes.c_void_p, ctypes.c_int, _ip]
     L.ndsm_hip_mg_set_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.ndsm_hip_mg_set_precision.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndsm_hip_mg_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
     L.ndsm_hip_mg_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
     L.ndsm_hip_mg_zero_rhs.argtypes = [ctypes.c_void_p]
@@ -164,6 +165,14 @@ class MGSolver:
     def zero_rhs(self):
         """rhs(1) == 0: the Laplace case of the vector potential; kernels then skip the rhs read"""
         _check(self.L.ndsm_hip_mg_zero_rhs(self.h), "zero_rhs", self.L)
+
+    def set_precision(self, mode):
+        """0 fp64, 1 mixed where level 1 is large, 2 mixed wherever the fp32 kernels apply;
+        returns True if solve() will run in mixed precision"""
+        rc = self.L.ndsm_hip_mg_set_precision(self.h, int(mode))
+        if rc < 0:
+            raise NdsmHipError(f"bad precision mode {mode}")
+        return rc == 1
 
     def op(self, op, level, count=1):
         _check(self.L.ndsm_hip_mg_op(self.h, op, level, count), f"op {op}", self.L)
@@ -314,9 +323,11 @@ def dist_init(rank, nranks, uid, lib=None):
 
 
 def poisson_solve(u, rhs, mesh, bcs, ms=5, ex_tol=1e-13, du_max=True, nmax_exact=10000, vc_tol=1e-10, nmax=1024,
-                  ngrids=0, hist_len=0, lib=None):
+                  ngrids=0, hist_len=0, lib=None, precision=0):
     """laplace(u) = rhs on the device.  u: initial guess + Dirichlet data,
-    numpy order (nz, ny, nx).  Returns (ierr, u, du_last, hist, ncycles)."""
+    numpy order (nz, ny, nx).  precision: 0 fp64 (reference arithmetic), 1 mixed (fp64 residual,
+    fp32 correction V-cycle on level 1) where level 1 is large enough, 2 mixed wherever possible.
+    Returns (ierr, u, du_last, hist, ncycles)."""
     L = lib or load_library()
     u = _f64(u).copy()
     nd = u.ndim
@@ -331,6 +342,7 @@ def poisson_solve(u, rhs, mesh, bcs, ms=5, ex_tol=1e-13, du_max=True, nmax_exact
     iopt[L.get_iopt_iopt_nmaxex()] = nmax_exact
     iopt[L.get_iopt_dumax()] = 1 if du_max else 0
     iopt[L.get_iopt_ngrids()] = ngrids
+    iopt[L.get_iopt_prec()] = precision
     ropt[L.get_ropt_vtol()] = vc_tol
     ropt[L.get_ropt_ctol()] = ex_tol
     hist = np.zeros(max(hist_len, 1))

@@ -68,7 +68,8 @@ typedef struct {
   int32_t f_beg, f_cnt;   /* local fine planes [f_beg, f_beg+f_cnt) are written by prolong_add */
   int32_t c_k0;           /* global index of plane 0 of the coarse array */
   int32_t c_beg, c_cnt;   /* local coarse planes [c_beg, c_beg+c_cnt) are written by restrict */
-  int32_t stream_ok;      /* host-checked: the LDS-streamed restriction (restrict_stream.hip) covers this pair */
+  int32_t stream_ok;      /* host-checked, restrict_stream.hip: bit 1 its tile covers this pair's taps,
+                             bit 0 and the level is large enough for it to be the default */
 } ndsmk_xfer;
 
 /* ---- runtime ------------------------------------------------------- */
@@ -135,6 +136,17 @@ int ndsmk_solve_exact(const ndsmk_grid *g, double *u, const double *rhs, double 
 int ndsmk_balance_curl(double *A, double *B, const int32_t *n3, const double *x, const double *y,
                        const double *z, const double *h_phi6, const double *h_span3,
                        const double *h_dq3, int curl_first);
+
+/* ---- mixed-precision mode (mixed.hip): level 1 as iterative refinement, correction in fp32 ---- */
+/* unew = u + e ; ezero = 0 ; r = (float)(rhs - L unew) ; h_out2 = (max|e|, sum|e|), blocking.
+ * e == NULL: r = residual of u, nothing else written.  rhs == NULL: zero right-hand side. */
+int ndsmk_update_residual_f32(const ndsmk_grid *g, const double *u, double *unew, const double *rhs, const float *e,
+                              float *ezero, float *r, double *h_out2);
+/* nsweeps fp32 sweeps of L e = r (fused kernel only); r_out != NULL: residual of the swept equation */
+int ndsmk_relax_f32(const ndsmk_grid *g, float *e, float *ealt, const float *r, int nsweeps, int force, float *r_out,
+                    int *result_in_alt);
+int ndsmk_restrict_f32(const ndsmk_xfer *x, const float *r_f, double *rhs_c, double *u_c);
+int ndsmk_prolong_add_f32(const ndsmk_xfer *x, const double *u_c, float *e_f);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,14 @@ __device__ __forceinline__ d2 ld2(const double *p) {
   r.y = t.y;
   return r;
 }
+// fp32 fine field (mixed-precision mode): converted on load, all arithmetic stays fp64
+__device__ __forceinline__ d2 ld2(const float *p) {
+  const float2 t = *reinterpret_cast<const float2 *>(p);
+  d2 r;
+  r.x = (double)t.x;
+  r.y = (double)t.y;
+  return r;
+}
 __device__ __forceinline__ void st2(double *p, const d2 a) {
   double2 t;
   t.x = a.x;
@@ -46,8 +54,8 @@ __device__ __forceinline__ void st2(double *p, const d2 a) {
   *reinterpret_cast<double2 *>(p) = t;
 }
 
-template <int CI, int CJ, int MT, int KCMAX>
-__global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const double *__restrict__ f, double *__restrict__ rhs_c,
+template <typename TF, int CI, int CJ, int MT, int KCMAX>
+__global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const TF *__restrict__ f, double *__restrict__ rhs_c,
                                                             double *__restrict__ u_c, RSArgs a) {
   constexpr int NT = CI * CJ;
   constexpr int FX = 2 * CI + 6, FY = 2 * CJ + 5;  // fine footprint of the tile (non-nested ratio up to ~2.03)
@@ -256,7 +264,8 @@ extern "C" void ndsmk_restrict_stream_tile(int *ci, int *cj, int *fx, int *fy, i
   *maxt = kMT;
 }
 
-int launch_restrict_stream(const ndsmk_xfer *x, const double *r_f, double *rhs_c, double *u_c) {
+template <typename TF>
+static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double *u_c) {
   RSArgs a;
   for (int d = 0; d < 3; ++d) {
     a.nf[d] = x->nf[d];
@@ -297,7 +306,7 @@ int launch_restrict_stream(const ndsmk_xfer *x, const double *r_f, double *rhs_c
   a.nwork = tiles * a.nkc;
   const int nblk = ((a.nwork + 7) / 8) * 8;
   constexpr size_t lds_bytes = sizeof(double) * 2 * (2 * kCI + 6) * (2 * kCJ + 5);
-  auto kfn = restrict_stream_k<kCI, kCJ, kMT, kKCMax>;
+  auto kfn = restrict_stream_k<TF, kCI, kCJ, kMT, kKCMax>;
   static bool attr_set = false;
   if (!attr_set) {
     NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -307,6 +316,13 @@ int launch_restrict_stream(const ndsmk_xfer *x, const double *r_f, double *rhs_c
   hipLaunchKernelGGL(kfn, dim3(nblk), dim3(kCI * kCJ), lds_bytes, stream(), r_f, rhs_c, u_c, a);
   NDSM_LAUNCH_CHECK();
   return 0;
+}
+
+int launch_restrict_stream(const ndsmk_xfer *x, const double *r_f, double *rhs_c, double *u_c) {
+  return launch_rs_t<double>(x, r_f, rhs_c, u_c);
+}
+int launch_restrict_stream_f32(const ndsmk_xfer *x, const float *r_f, double *rhs_c, double *u_c) {
+  return launch_rs_t<float>(x, r_f, rhs_c, u_c);
 }
 
 }  // namespace ndsm

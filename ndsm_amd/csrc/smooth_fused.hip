@@ -40,32 +40,43 @@ struct FusedPlan {
   int nwork;          // ntx * nty * nzc
 };
 
-// an x-pair; elements are picked with selects (a runtime-indexed register
-// array would be demoted to scratch memory)
-struct d2 {
-  double x, y;
+// an x-pair of the working precision T (double: the reference's arithmetic; float: the
+// correction equation of the mixed-precision mode); elements are picked with selects (a
+// runtime-indexed register array would be demoted to scratch memory)
+template <typename T>
+struct P2 {
+  T x, y;
+};
+template <typename T>
+struct Vec2;
+template <>
+struct Vec2<double> {
+  using type = double2;
+};
+template <>
+struct Vec2<float> {
+  using type = float2;
 };
 
-__device__ __forceinline__ d2 ld2(const double *p) {
-  const double2 t = *reinterpret_cast<const double2 *>(p);
-  d2 r;
+template <typename T>
+__device__ __forceinline__ P2<T> ld2(const T *p) {
+  const typename Vec2<T>::type t = *reinterpret_cast<const typename Vec2<T>::type *>(p);
+  P2<T> r;
   r.x = t.x;
   r.y = t.y;
   return r;
 }
-__device__ __forceinline__ void st2(double *p, const d2 &a) {
-  double2 t;
+template <typename T>
+__device__ __forceinline__ void st2(T *p, const P2<T> &a) {
+  typename Vec2<T>::type t;
   t.x = a.x;
   t.y = a.y;
-  *reinterpret_cast<double2 *>(p) = t;
+  *reinterpret_cast<typename Vec2<T>::type *>(p) = t;
 }
 // by value: selects on values, never on addresses
-__device__ __forceinline__ double pick(const d2 a, int e) { return e ? a.y : a.x; }
-[[maybe_unused]] __device__ __forceinline__ d2 put(const d2 a, int e, double v) {
-  d2 r;
-  r.x = e ? a.x : v;
-  r.y = e ? v : a.y;
-  return r;
+template <typename T>
+__device__ __forceinline__ T pick(const P2<T> a, int e) {
+  return e ? a.y : a.x;
 }
 
 // geometry of slot s of this thread, recomputed where needed (cheap integer
@@ -116,10 +127,13 @@ struct Slot {
 // stage needs plane k-2S with its in-plane neighbours (one more LDS buffer) and
 // the thread's own pairs of planes k-2S+1 and k-2S-1 (registers); halo and chunk
 // warm-up grow by one.
-template <int S, int TXH, int TYH, int NT, int WPS, bool RHS0, bool RES>
-__global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restrict__ u, double *__restrict__ uout,
-                                                         const double *__restrict__ rhs, double *__restrict__ rout,
+template <typename T, int S, int TXH, int TYH, int NT, int WPS, bool RHS0, bool RES>
+__global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u, T *__restrict__ uout,
+                                                         const T *__restrict__ rhs, T *__restrict__ rout,
                                                          ndsmk_grid g, FusedPlan pl) {
+  using d2 = P2<T>;
+  constexpr int SZ = (int)sizeof(T);
+  const T gw0 = (T)g.w[0], gw1 = (T)g.w[1], gw2 = (T)g.w[2], gw1i = (T)g.w1, gwc = (T)g.wc;
   constexpr int NST = 2 * S;                 // smoothing stages
   constexpr int NSTG = RES ? NST + 1 : NST;  // pipeline depth = LDS planes = halo width
   constexpr int NPX = TXH / 2;
@@ -130,7 +144,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
   constexpr int PLANE = TXH * TYH;
   constexpr int BIG = 1 << 20;
   using SlotT = Slot<TXH, TYH, NT, HX, NSTG>;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  T *const lds = reinterpret_cast<T *>(lds_raw);
 
   // ---- which (tile, chunk): consecutive y tiles share an XCD ---------
   const int nb8 = gridDim.x >> 3;
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 
 #define NDSM_LOAD_PLANE(base, k, dst)                              \
   do {                                                              \
-    const double *pk_ = (base) + sz * (size_t)(k);                  \
+    const T *pk_ = (base) + sz * (size_t)(k);                  \
     _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {             \
       const SlotT q_(tid, s_, x0, y0, nx, ny);                      \
       d2 t_;                                                        \
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
   d2 nxt[NS], nn[NS];
   //   RES: f1 / f2 = the final pairs of planes k-2S and k-2S-1
   d2 rw[RHS0 ? 1 : NS][RHS0 ? 1 : NSTG], rn[RHS0 ? 1 : NS];
-  double mLe[RES ? 1 : NS];
+  T mLe[RES ? 1 : NS];
   d2 f1[RES ? NS : 1], f2[RES ? NS : 1];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -212,12 +227,12 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
   auto make_sc = [&](int tid_, int s) {
     const SlotT q(tid_, s, x0, y0, nx, ny);
     SC c;
-    c.lo = 8 * q.lo;
+    c.lo = SZ * q.lo;
     c.go = q.i + nx * q.j;
     // rows whose y neighbours fall outside the loaded tile can never be updated: ring 0
     const bool yok = q.lj + (q.j == 0 ? 1 : -1) >= 0 && q.lj + (q.j == ny - 1 ? -1 : 1) < TYH;
-    c.yl = !yok ? 0 : ((q.j == 0) ? 8 * TXH : -8 * TXH);
-    c.yh = !yok ? 0 : ((q.j == ny - 1) ? -8 * TXH : 8 * TXH);
+    c.yl = !yok ? 0 : ((q.j == 0) ? SZ * TXH : -SZ * TXH);
+    c.yh = !yok ? 0 : ((q.j == ny - 1) ? -SZ * TXH : SZ * TXH);
     const bool yin = q.j >= g.lb[1] && q.j <= g.ub[1];
     const bool in0 = yin && q.i >= g.lb[0] && q.i <= g.ub[0];
     const bool in1 = yin && q.i + 1 >= g.lb[0] && q.i + 1 <= g.ub[0];
@@ -231,8 +246,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
     if (!yok || !q.in) r0 = r1 = 0;
     if (!in0) r0 = 0;
     if (!in1) r1 = 0;
-    c.xlo = mir0 ? c.lo + 8 : (q.li - 1 >= 0 ? c.lo - 8 : c.lo);
-    c.xhi = mir1 ? c.lo : (q.li + 2 < TXH ? c.lo + 16 : c.lo + 8);
+    c.xlo = mir0 ? c.lo + SZ : (q.li - 1 >= 0 ? c.lo - SZ : c.lo);
+    c.xhi = mir1 ? c.lo : (q.li + 2 < TXH ? c.lo + 2 * SZ : c.lo + SZ);
     int fl = (q.in ? 1 : 0) | (q.own ? 2 : 0) | (in0 ? 4 : 0) | (in1 ? 8 : 0);
     fl |= ((q.i + q.j + g.k0 + fp) & 1) ? 64 : 0;
     fl |= min(r0, 15) << 8;
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 #pragma unroll
   for (int s = 0; s < NS; ++s) scs[s] = make_sc(tid, s);
   char *const ldsb = reinterpret_cast<char *>(lds);
-#define LDSD(off) (*reinterpret_cast<double *>(ldsb + (off)))
+#define LDSD(off) (*reinterpret_cast<T *>(ldsb + (off)))
 
   // ---- prologue: plane ks into its LDS buffer, plane ks+1 into registers ----
   {
@@ -259,7 +274,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rw[s][0] = r0[s];
     }
     if (ks + 1 <= ke) NDSM_LOAD_PLANE(u, ks + 1, nxt);
-    double *B0 = lds + (ks % NSTG) * PLANE;
+    T *B0 = lds + (ks % NSTG) * PLANE;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const SlotT q(tid, s, x0, y0, nx, ny);
@@ -281,17 +296,17 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       } else {
         b = (k - d) & (NST - 1);
       }
-      return b * (PLANE * 8);
+      return b * (PLANE * SZ);
     };
     // request plane k+2 of u and plane k+1 of rhs before touching plane k
     if (k + 2 <= ke) {
-      const double *pk = u + sz * (size_t)(k + 2);
+      const T *pk = u + sz * (size_t)(k + 2);
 #pragma unroll
       for (int s = 0; s < NS; ++s)
         if (scs[s].fl & 1) nn[s] = ld2(pk + scs[s].go);
     }
     if (!RHS0 && k + 1 <= ke) {
-      const double *pk = rhs + sz * (size_t)(k + 1);
+      const T *pk = rhs + sz * (size_t)(k + 1);
 #pragma unroll
       for (int s = 0; s < (RHS0 ? 1 : NS); ++s)
         if (scs[s].fl & 1) rn[s] = ld2(pk + scs[s].go);
@@ -299,14 +314,14 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 
     // ---- this iteration's element of every pair (the same for all stages) ----
     int ee[NS], eB[NS], oB[NS], xB[NS], lim[NS];
-    double zplus[NS];
+    T zplus[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const SC c = scs[s];
       const int e = ((c.fl >> 6) + k) & 1;
       ee[s] = e;
-      eB[s] = c.lo + 8 * e;      // the element, its pair partner, its outer x neighbour
-      oB[s] = c.lo + 8 - 8 * e;
+      eB[s] = c.lo + SZ * e;      // the element, its pair partner, its outer x neighbour
+      oB[s] = c.lo + SZ - SZ * e;
       xB[s] = e ? c.xhi : c.xlo;
       lim[s] = (c.fl >> (8 + 4 * e)) & 15;  // stage t may update it iff lim > t
       zplus[s] = pick(nxt[s], e);           // plane k+1, untouched by any stage yet
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       const int bZ = bufoff(t + 1);
       const bool pin = p >= g.lb[2] && p <= g.ub[2];
       const int pg = p + g.k0;
-      double cur[NS], oth[NS], xn[NS], yhv[NS], ylv[NS], zm[NS];
+      T cur[NS], oth[NS], xn[NS], yhv[NS], ylv[NS], zm[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         cur[s] = LDSD(bB + eB[s]);
@@ -336,14 +351,14 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const double xs = oth[s] + xn[s];  // u(xh) + u(xl)
-        const double ys = yhv[s] + ylv[s];
-        const double zhv = (pg == g.nzg - 1) ? zm[s] : zplus[s];
-        const double zlv = (pg == 0) ? zplus[s] : zm[s];
-        const double zsum = zhv + zlv;
-        const double rr = RHS0 ? 0.0 : pick(rw[RHS0 ? 0 : s][RHS0 ? 0 : t], ee[s]);
-        const double unew = xs * g.w[0] + ys * g.w[1] + zsum * g.w[2] - rr;
-        const double nw = g.w1 * unew;
+        const T xs = oth[s] + xn[s];  // u(xh) + u(xl)
+        const T ys = yhv[s] + ylv[s];
+        const T zhv = (pg == g.nzg - 1) ? zm[s] : zplus[s];
+        const T zlv = (pg == 0) ? zplus[s] : zm[s];
+        const T zsum = zhv + zlv;
+        const T rr = RHS0 ? (T)0 : pick(rw[RHS0 ? 0 : s][RHS0 ? 0 : t], ee[s]);
+        const T unew = xs * gw0 + ys * gw1 + zsum * gw2 - rr;
+        const T nw = gw1i * unew;
         const bool upd = pin && lim[s] > t;
         if (upd) LDSD(bB + eB[s]) = nw;
         zplus[s] = upd ? nw : cur[s];  // z+1 neighbour of the next stage's plane
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       d2 fin;
       fin.x = fin.y = 0.0;
       if (pf >= ks) {
-        fin = ld2(reinterpret_cast<const double *>(ldsb + bufoff(NST - 1) + c.lo));
+        fin = ld2(reinterpret_cast<const T *>(ldsb + bufoff(NST - 1) + c.lo));
         if (pf >= zs && pf < ze && (fl & 2)) st2(uout + sz * (size_t)pf + c.go, fin);
         if (!RES) mLe[RES ? 0 : s] = pick(fin, 1 - ee[s]);
       }
@@ -370,10 +385,10 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
         const d2 cc = f1[RES ? s : 0], below = f2[RES ? s : 0];
         if (pr >= zs && pr < ze && (fl & 2)) {
           const int bR = bufoff(NST);
-          const double xl0 = LDSD(bR + c.xlo);
-          const double xh1 = LDSD(bR + c.xhi);
-          const d2 vl = ld2(reinterpret_cast<const double *>(ldsb + bR + c.lo + c.yl));
-          const d2 vh = ld2(reinterpret_cast<const double *>(ldsb + bR + c.lo + c.yh));
+          const T xl0 = LDSD(bR + c.xlo);
+          const T xh1 = LDSD(bR + c.xhi);
+          const d2 vl = ld2(reinterpret_cast<const T *>(ldsb + bR + c.lo + c.yl));
+          const d2 vh = ld2(reinterpret_cast<const T *>(ldsb + bR + c.lo + c.yh));
           const int prg = pr + g.k0;
           const d2 wl = (prg == 0) ? fin : below;
           const d2 wh = (prg == g.nzg - 1) ? below : fin;
@@ -381,11 +396,11 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
           d2 rr;
           rr.x = rr.y = 0.0;
           if (!RHS0) rr = rw[RHS0 ? 0 : s][RHS0 ? 0 : NST];
-          const double v0 = (xl0 + cc.y) * g.w[0] + (vl.x + vh.x) * g.w[1] + (wl.x + wh.x) * g.w[2] - rr.x - cc.x * g.wc;
-          const double v1 = (cc.x + xh1) * g.w[0] + (vl.y + vh.y) * g.w[1] + (wl.y + wh.y) * g.w[2] - rr.y - cc.y * g.wc;
+          const T v0 = (xl0 + cc.y) * gw0 + (vl.x + vh.x) * gw1 + (wl.x + wh.x) * gw2 - rr.x - cc.x * gwc;
+          const T v1 = (cc.x + xh1) * gw0 + (vl.y + vh.y) * gw1 + (wl.y + wh.y) * gw2 - rr.y - cc.y * gwc;
           d2 res;
-          res.x = (inz && (fl & 4)) ? -v0 : 0.0;
-          res.y = (inz && (fl & 8)) ? -v1 : 0.0;
+          res.x = (inz && (fl & 4)) ? -v0 : (T)0;
+          res.y = (inz && (fl & 8)) ? -v1 : (T)0;
           st2(rout + sz * (size_t)pr + c.go, res);
         }
         f2[RES ? s : 0] = cc;
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
       char *bn = ldsb + bufoff(-1);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        if (k + 1 <= ke && tid0 + NT * s < NPAIR) st2(reinterpret_cast<double *>(bn + scs[s].lo), nxt[s]);
+        if (k + 1 <= ke && tid0 + NT * s < NPAIR) st2(reinterpret_cast<T *>(bn + scs[s].lo), nxt[s]);
         nxt[s] = nn[s];
       }
       if (!RHS0) {
@@ -419,9 +434,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const double *__restric
 #undef NDSM_LOAD_PLANE
 }
 
-template <int S, int TXH, int TYH, int NT, int WPS, bool RES = false>
-int launch_cfg(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int target_wgs,
-               double *rout = nullptr) {
+template <typename T, int S, int TXH, int TYH, int NT, int WPS, bool RES = false>
+int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int target_wgs, T *rout = nullptr) {
   constexpr int NST = RES ? 2 * S + 1 : 2 * S;
   constexpr int TXI = TXH - 2 * ((NST + 1) & ~1), TYI = TYH - 2 * NST;
   static_assert(TXI > 0 && TYI > 0 && (TXH % 2) == 0, "tile");
@@ -430,20 +444,20 @@ int launch_cfg(const ndsmk_grid &g, const double *u, double *uout, const double 
   pl.nty = (g.n[1] + TYI - 1) / TYI;
   const int tiles = pl.ntx * pl.nty;
   const int nzo = g.zown1 - g.zown0;  // owned planes
-  const size_t lds_bytes = sizeof(double) * NST * TXH * TYH;
+  const size_t lds_bytes = sizeof(T) * NST * TXH * TYH;
   static bool attr_set[2] = {false, false};
   static int wgs_per_cu[2] = {1, 1};
   const int v = rhs ? 0 : 1;
-  const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<S, TXH, TYH, NT, WPS, false, RES>)
-                         : reinterpret_cast<const void *>(rbgs3_fused_k<S, TXH, TYH, NT, WPS, true, RES>);
+  const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, RES>)
+                         : reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, RES>);
   if (!attr_set[v]) {
     NDSM_HIP(hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int occ = 1;
     if (rhs)
-      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<S, TXH, TYH, NT, WPS, false, RES>, NT,
+      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, RES>, NT,
                                                             lds_bytes));
     else
-      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<S, TXH, TYH, NT, WPS, true, RES>, NT,
+      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, RES>, NT,
                                                             lds_bytes));
     wgs_per_cu[v] = occ > 0 ? occ : 1;
     attr_set[v] = true;
@@ -478,12 +492,12 @@ int launch_cfg(const ndsmk_grid &g, const double *u, double *uout, const double 
   pl.nwork = tiles * pl.nzc;
   const int nblk = ((pl.nwork + 7) / 8) * 8;
   if (rhs)
-    hipLaunchKernelGGL((rbgs3_fused_k<S, TXH, TYH, NT, WPS, false, RES>), dim3(nblk), dim3(NT), lds_bytes,
+    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, RES>), dim3(nblk), dim3(NT), lds_bytes,
                        ndsm::stream(), u, uout, rhs, rout, g, pl);
   else  // the level's rhs is identically zero (level 1 of NDSM's Laplace problems,
         // ndsm_vector_potential.f90:640-641): x - 0.0 == x exactly, so the variant that never
         // loads rhs returns the same bits with 8 B/LUP less traffic
-    hipLaunchKernelGGL((rbgs3_fused_k<S, TXH, TYH, NT, WPS, true, RES>), dim3(nblk), dim3(NT), lds_bytes,
+    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, RES>), dim3(nblk), dim3(NT), lds_bytes,
                        ndsm::stream(), u, uout, rhs, rout, g, pl);
   NDSM_LAUNCH_CHECK();
   return 0;
@@ -512,8 +526,9 @@ static const int *fused_cfg() {
 // rout != nullptr: the caller wants the residual of the swept field as well.  It is
 // produced (and *res_done set) only by the launch that performs the LAST of the
 // max_sweeps sweeps, i.e. when this call runs a single sweep with max_sweeps == 1.
-int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
-                       bool force, int *sweeps_done, double *rout, int *res_done) {
+template <typename T>
+static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int max_sweeps, bool force,
+                          int *sweeps_done, T *rout, int *res_done) {
   *sweeps_done = 0;
   if (res_done) *res_done = 0;
   if (!uout || g.ndim != 3 || (g.n[0] & 1) || g.n[0] < 16 || g.n[1] < 16 || g.zown1 - g.zown0 < 8) return 0;
@@ -537,9 +552,9 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
   const bool two = max_sweeps >= 2 && ghosts >= 4 && cfg[0] != 9 && !(res && max_sweeps == 2);
   if (two) {
     switch (cfg[0]) {
-      case 3: rc = launch_cfg<2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;
-      case 5: rc = launch_cfg<2, 72, 28, 512, 4>(g, u, uout, rhs, tgt); break;
-      default: rc = launch_cfg<2, 136, 30, 1024, 4>(g, u, uout, rhs, tgt); break;
+      case 3: rc = launch_cfg<T, 2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;
+      case 5: rc = launch_cfg<T, 2, 72, 28, 512, 4>(g, u, uout, rhs, tgt); break;
+      default: rc = launch_cfg<T, 2, 136, 30, 1024, 4>(g, u, uout, rhs, tgt); break;
     }
     if (rc) return rc;
     *sweeps_done = 2;
@@ -547,8 +562,8 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
   }
   if (res && max_sweeps == 1) {
     switch (cfg[2]) {
-      case 1: rc = (launch_cfg<1, 136, 30, 1024, 4, true>(g, u, uout, rhs, tgt, rout)); break;
-      default: rc = (launch_cfg<1, 136, 22, 768, 4, true>(g, u, uout, rhs, tgt, rout)); break;
+      case 1: rc = (launch_cfg<T, 1, 136, 30, 1024, 4, true>(g, u, uout, rhs, tgt, rout)); break;
+      default: rc = (launch_cfg<T, 1, 136, 22, 768, 4, true>(g, u, uout, rhs, tgt, rout)); break;
     }
     if (rc) return rc;
     *sweeps_done = 1;
@@ -556,12 +571,24 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
     return 0;
   }
   switch (cfg[1] ? cfg[1] : (big ? 7 : 8)) {
-    case 8: rc = launch_cfg<1, 132, 23, 768, 4>(g, u, uout, rhs, tgt); break;
-    default: rc = launch_cfg<1, 132, 31, 1024, 4>(g, u, uout, rhs, tgt); break;
+    case 8: rc = launch_cfg<T, 1, 132, 23, 768, 4>(g, u, uout, rhs, tgt); break;
+    default: rc = launch_cfg<T, 1, 132, 31, 1024, 4>(g, u, uout, rhs, tgt); break;
   }
   if (rc) return rc;
   *sweeps_done = 1;
   return 0;
+}
+
+int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
+                       bool force, int *sweeps_done, double *rout, int *res_done) {
+  return launch_fused_t<double>(g, u, uout, rhs, max_sweeps, force, sweeps_done, rout, res_done);
+}
+
+// fp32 instantiation: the correction equation L e = r of the mixed-precision mode (same tiles:
+// half the LDS and HBM bytes per point, the same instruction count)
+int launch_rbgs3_fused_f32(const ndsmk_grid &g, const float *u, float *uout, const float *rhs, int max_sweeps,
+                           bool force, int *sweeps_done, float *rout, int *res_done) {
+  return launch_fused_t<float>(g, u, uout, rhs, max_sweeps, force, sweeps_done, rout, res_done);
 }
 
 }  // namespace ndsm

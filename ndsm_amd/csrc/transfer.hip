@@ -19,6 +19,7 @@
 
 namespace ndsm {
 int launch_restrict_stream(const ndsmk_xfer *x, const double *r_f, double *rhs_c, double *u_c);
+int launch_restrict_stream_f32(const ndsmk_xfer *x, const float *r_f, double *rhs_c, double *u_c);
 }
 
 namespace {
@@ -126,7 +127,10 @@ __global__ __launch_bounds__(256) void prolong_add_k(const double *__restrict__ 
 constexpr int PT_X = 64, PT_Y = 8, PT_Z = 8;
 constexpr int PC_X = 36, PC_Y = 7, PC_Z = 7;
 
-__global__ __launch_bounds__(256) void prolong_tile_k(const double *__restrict__ uc, double *__restrict__ uf,
+// TF: type of the fine field (float: the correction e of the mixed-precision mode; the
+// interpolation and the addition are fp64, the sum is rounded once on the way out)
+template <typename TF>
+__global__ __launch_bounds__(256) void prolong_tile_k(const double *__restrict__ uc, TF *__restrict__ uf,
                                                       XferDev x) {
   __shared__ double C[PC_Z][PC_Y][PC_X];
   const int i0 = blockIdx.x * PT_X, j0 = blockIdx.y * PT_Y;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void prolong_tile_k(const double *__restrict__
       f1 = why * f1 + wly * f3;
       const double v = whx * f0 + wlx * f1;
       const size_t c = (size_t)i + (size_t)x.nf[0] * ((size_t)j + (size_t)x.nf[1] * (size_t)kl);
-      uf[c] = uf[c] + v;
+      uf[c] = (TF)((double)uf[c] + v);
     }
   }
 }
@@ -213,7 +217,7 @@ extern "C" int ndsmk_restrict(const ndsmk_xfer *x, const double *r_f, double *rh
   XferDev d;
   int ndim;
   if (int rc = to_dev(x, &d, &ndim)) return rc;
-  if (ndim == 3 && x->stream_ok) return ndsm::launch_restrict_stream(x, r_f, rhs_c, u_c);
+  if (ndim == 3 && (x->stream_ok & 1)) return ndsm::launch_restrict_stream(x, r_f, rhs_c, u_c);
   dim3 block(32, 8, 1);
   dim3 grid((d.nc[0] + 31) / 32, (d.nc[1] + 7) / 8, d.c_cnt);
   if (ndim == 3)
@@ -236,7 +240,7 @@ extern "C" int ndsmk_prolong_add(const ndsmk_xfer *x, const double *u_c, double 
   if (ndim == 3 && (int64_t)d.nf[0] * d.nf[1] * d.f_cnt >= (int64_t)1 << 21 && d.nf[0] >= 64 && d.nc[0] >= 16 &&
       d.nc[1] >= 16 && d.nc[2] >= 16) {
     dim3 g2((d.nf[0] + PT_X - 1) / PT_X, (d.nf[1] + PT_Y - 1) / PT_Y, (d.f_cnt + PT_Z - 1) / PT_Z);
-    hipLaunchKernelGGL(prolong_tile_k, g2, block, 0, ndsm::stream(), u_c, u_f, d);
+    hipLaunchKernelGGL(prolong_tile_k<double>, g2, block, 0, ndsm::stream(), u_c, u_f, d);
     NDSM_LAUNCH_CHECK();
     return 0;
   }
@@ -244,6 +248,32 @@ extern "C" int ndsmk_prolong_add(const ndsmk_xfer *x, const double *u_c, double 
     hipLaunchKernelGGL(prolong_add_k<3>, grid, block, 0, ndsm::stream(), u_c, u_f, d);
   else
     hipLaunchKernelGGL(prolong_add_k<2>, grid, block, 0, ndsm::stream(), u_c, u_f, d);
+  NDSM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- mixed-precision mode: level-1 side in fp32 (see mixed.hip) -------------------------
+// Only the large-level kernels exist in this flavour; the caller checks stream_ok.
+extern "C" int ndsmk_restrict_f32(const ndsmk_xfer *x, const float *r_f, double *rhs_c, double *u_c) {
+  NDSM_REQUIRE_READY();
+  XferDev d;
+  int ndim;
+  if (int rc = to_dev(x, &d, &ndim)) return rc;
+  if (ndim != 3 || !(x->stream_ok & 2))
+    return ndsm::fail(NDSMK_EARG, "fp32 restriction: the streamed kernel does not cover this level pair", __FILE__, __LINE__);
+  return ndsm::launch_restrict_stream_f32(x, r_f, rhs_c, u_c);
+}
+
+extern "C" int ndsmk_prolong_add_f32(const ndsmk_xfer *x, const double *u_c, float *e_f) {
+  NDSM_REQUIRE_READY();
+  XferDev d;
+  int ndim;
+  if (int rc = to_dev(x, &d, &ndim)) return rc;
+  if (!(ndim == 3 && d.nf[0] >= 64 && d.nc[0] >= 16 && d.nc[1] >= 16 && d.nc[2] >= 16))
+    return ndsm::fail(NDSMK_EARG, "fp32 prolongation: the tiled kernel does not cover this level pair", __FILE__, __LINE__);
+  dim3 block(64, 4, 1);
+  dim3 g2((d.nf[0] + PT_X - 1) / PT_X, (d.nf[1] + PT_Y - 1) / PT_Y, (d.f_cnt + PT_Z - 1) / PT_Z);
+  hipLaunchKernelGGL(prolong_tile_k<float>, g2, block, 0, ndsm::stream(), u_c, e_f, d);
   NDSM_LAUNCH_CHECK();
   return 0;
 }

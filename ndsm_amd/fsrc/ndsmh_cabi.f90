@@ -188,6 +188,10 @@ contains
     integer(c_int) :: v
     v = IOPT_NGRIDS
   end function
+  function get_iopt_prec() bind(c, name="get_iopt_prec") result(v)
+    integer(c_int) :: v
+    v = IOPT_PREC
+  end function
   function get_iopt_ncyc_out() bind(c, name="get_iopt_ncyc_out") result(v)
     integer(c_int) :: v
     v = IOPT_NCYC_OUT
@@ -277,11 +281,13 @@ contains
       call c_f_pointer(hist, hh, [hist_len])
       rc = poisson_solve(int(ndim), n3, qx, qy, qz, bc, int(ioptc(IOPT_MS)), ropt(ROPT_CTOL), &
                          ioptc(IOPT_DUMAX) == 1, int(ioptc(IOPT_NMAXEX)), int(ioptc(IOPT_NGRIDS)), &
-                         ropt(ROPT_VTOL), int(ioptc(IOPT_NCYCLES)), u, rhs, du_last, ncyc, ie, hh)
+                         ropt(ROPT_VTOL), int(ioptc(IOPT_NCYCLES)), u, rhs, du_last, ncyc, ie, hh, &
+                         precision=int(ioptc(IOPT_PREC)))
     else
       rc = poisson_solve(int(ndim), n3, qx, qy, qz, bc, int(ioptc(IOPT_MS)), ropt(ROPT_CTOL), &
                          ioptc(IOPT_DUMAX) == 1, int(ioptc(IOPT_NMAXEX)), int(ioptc(IOPT_NGRIDS)), &
-                         ropt(ROPT_VTOL), int(ioptc(IOPT_NCYCLES)), u, rhs, du_last, ncyc, ie)
+                         ropt(ROPT_VTOL), int(ioptc(IOPT_NCYCLES)), u, rhs, du_last, ncyc, ie, &
+                         precision=int(ioptc(IOPT_PREC)))
     end if
     ropt(ROPT_TIM) = wall_seconds() - t0
     if (rc /= 0) then
@@ -375,6 +381,20 @@ contains
     call c_f_pointer(handle, s)
     s%ms = ms
     rc = 0
+  end function
+
+  ! 0: fp64 (reference arithmetic); 1: mixed precision where level 1 is large enough; 2: mixed
+  ! wherever the fp32 kernels cover level 1.  Returns 1 if ndsm_hip_mg_solve will run mixed, else 0.
+  function ndsm_hip_mg_set_precision(handle, mode) bind(c, name="ndsm_hip_mg_set_precision") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int), value :: mode
+    integer(c_int) :: rc
+    type(mg_solver), pointer :: s
+    call c_f_pointer(handle, s)
+    rc = -1
+    if (mode < 0 .or. mode > 2) return
+    s%precision = mode
+    rc = merge(1_c_int, 0_c_int, mg_mixed_applies(s))
   end function
 
   ! which: 0 = u, 1 = rhs, 2 = residual scratch (level-1 sized, valid after op RESIDUAL)

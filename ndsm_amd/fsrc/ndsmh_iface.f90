@@ -135,6 +135,39 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_update_residual_f32(g, u, unew, rhs, e, ezero, r, h_out2) &
+        bind(c, name="ndsmk_update_residual_f32") result(rc)
+      import :: ndsmk_grid, c_ptr, c_int, c_double
+      type(ndsmk_grid), intent(in) :: g
+      type(c_ptr), value :: u, unew, rhs, e, ezero, r
+      real(c_double), intent(out) :: h_out2(2)
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_relax_f32(g, e, ealt, r, nsweeps, force, r_out, result_in_alt) &
+        bind(c, name="ndsmk_relax_f32") result(rc)
+      import :: ndsmk_grid, c_ptr, c_int
+      type(ndsmk_grid), intent(in) :: g
+      type(c_ptr), value :: e, ealt, r, r_out
+      integer(c_int), value :: nsweeps, force
+      integer(c_int), intent(out) :: result_in_alt
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_restrict_f32(x, r_f, rhs_c, u_c) bind(c, name="ndsmk_restrict_f32") result(rc)
+      import :: ndsmk_xfer, c_ptr, c_int
+      type(ndsmk_xfer), intent(in) :: x
+      type(c_ptr), value :: r_f, rhs_c, u_c
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_prolong_add_f32(x, u_c, e_f) bind(c, name="ndsmk_prolong_add_f32") result(rc)
+      import :: ndsmk_xfer, c_ptr, c_int
+      type(ndsmk_xfer), intent(in) :: x
+      type(c_ptr), value :: u_c, e_f
+      integer(c_int) :: rc
+    end function
+
     function ndsmk_residual(g, u, rhs, r) bind(c, name="ndsmk_residual") result(rc)
       import :: ndsmk_grid, c_ptr, c_int
       type(ndsmk_grid), intent(in) :: g

@@ -25,6 +25,7 @@ module ndsmh_mg
   private
 
   public :: mg_solver, mg_create, mg_destroy, mg_vcycle, mg_solve
+  public :: mg_mixed_applies
   public :: mg_set_u, mg_set_rhs, mg_get_u, mg_zero_rhs, mg_level_ptr, mg_op, mg_read_info
   public :: mg_mark_rhs_set
   public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
@@ -67,6 +68,8 @@ module ndsmh_mg
     integer(ik) :: npts1 = 0             ! elements of the level-1 device arrays (local window if z-slab)
     logical :: rhs1_zero = .false.        ! level-1 rhs is identically zero: kernels skip reading it
     logical :: allow_fused_rr = .false.  ! resrest.hip is correct but not yet faster than residual + streamed restriction
+    integer :: precision = 0             ! 0 fp64 (reference arithmetic), 1 mixed where level 1 is large enough,
+                                         ! 2 mixed wherever the fp32 kernels cover level 1 (tests)
     ! ---- z-slab mode (level 1 distributed, SURVEY 8e); unused otherwise
     logical :: slab = .false.
     logical :: has_coarse = .true.       ! levels >= 2 live here (rank 0 only when distributed)
@@ -195,7 +198,7 @@ contains
     end do
     rc = ndsmk_alloc(s%xf(l)%blob, total); if (rc /= 0) return
     s%xf(l)%fused_rr = fused_rr_applies(s, l, t)
-    s%xf(l)%x%stream_ok = merge(1, 0, stream_restrict_applies(s, l, t))
+    s%xf(l)%x%stream_ok = stream_restrict_applies(s, l, t)
 
     s%xf(l)%x%nf = s%lev(l)%n
     s%xf(l)%x%nc = s%lev(l + 1)%n
@@ -235,17 +238,18 @@ contains
 
   ! Does restrict_stream.hip cover the transfer l -> l+1?  Same idea as below,
   ! with that kernel's footprint (no stencil halo).
+  ! bit 1: the kernel's tile covers every coarse tile's taps; bit 0: and the level is large
+  ! enough for it to be the default choice
   function stream_restrict_applies(s, l, t) result(ok)
     type(mg_solver), intent(in) :: s
     integer, intent(in) :: l
     type(axis_xfer_t), intent(in) :: t(3)
-    logical :: ok
+    integer(c_int) :: ok
     integer(c_int) :: ci, cj, fx, fy, mt
     integer :: a0, a1, f0, nt, k
-    ok = .false.
+    ok = 0
     if (s%ndim /= 3) return
     if (mod(s%lev(l)%n(1), 2) /= 0) return
-    if (s%lev(l)%npts < 6_ik * 1024_ik * 1024_ik) return
     call ndsmk_restrict_stream_tile(ci, cj, fx, fy, mt)
     if (any([t(1)%maxt, t(2)%maxt, t(3)%maxt] > mt)) return
     nt = (t(1)%nc + ci - 1) / ci
@@ -260,7 +264,8 @@ contains
       f0 = t(2)%rlo(a0)
       if (t(2)%rlo(a1) + t(2)%rcnt(a1) - 1 > f0 + fy - 1) return
     end do
-    ok = .true.
+    ok = 2
+    if (s%lev(l)%npts >= 6_ik * 1024_ik * 1024_ik) ok = 3
   end function
 
   ! Does resrest.hip cover the transfer l -> l+1?  3-D, even nx, a level large
@@ -565,6 +570,10 @@ contains
     real(wp) :: met(2), du
     integer :: it
 
+    if (mg_mixed_applies(s)) then
+      rc = mg_solve_mixed(s, vc_tol, nmax, du_last, ncycles, ierr, hist)
+      return
+    end if
     du = huge(du)
     ncycles = 0
     ierr = 1
@@ -573,6 +582,93 @@ contains
     do it = 1, nmax
       rc = mg_vcycle(s); if (rc /= 0) return
       rc = ndsmk_diff_metrics(s%dl(1)%u, s%prev, s%npts1, 1_c_int, met); if (rc /= 0) return
+      if (s%use_max) then
+        du = met(1)
+      else
+        du = met(2) / real(s%npts1, wp)
+      end if
+      ncycles = it
+      if (present(hist)) then
+        if (it <= size(hist)) hist(it) = du
+      end if
+      if (du < vc_tol) then         ! strict (:136)
+        ierr = 0
+        exit
+      end if
+    end do
+    du_last = du
+    rc = 0
+  end function
+
+  ! ------------------------------------------------------------------
+  ! Mixed-precision mode (BASELINE config[4]; csrc/mixed.hip has the algebra).
+  ! ------------------------------------------------------------------
+  ! Is the solve run as fp64 residual + fp32 correction V-cycle?  Asked for, 3-D, single domain,
+  ! >= 2 grids, ms >= 1, and level 1 within reach of the fp32 kernels (fused smoother, streamed
+  ! restriction, tiled prolongation); otherwise the fp64 path runs.
+  function mg_mixed_applies(s) result(ok)
+    type(mg_solver), intent(in) :: s
+    logical :: ok
+    ok = .false.
+    if (s%precision == 0 .or. s%ndim /= 3 .or. s%slab .or. s%ngrids < 2 .or. s%ms < 1) return
+    if (s%lev(1)%g%all_neumann /= 0) return
+    if (mod(s%lev(1)%n(1), 2) /= 0 .or. s%lev(1)%n(1) < 64 .or. s%lev(1)%n(2) < 16 .or. s%lev(1)%n(3) < 8) return
+    if (any(s%lev(2)%n(1:3) < 16)) return
+    if (iand(int(s%xf(1)%x%stream_ok), 2) == 0) return
+    if (s%precision == 1 .and. s%lev(1)%npts < 6_ik * 1024_ik * 1024_ik) return
+    ok = .true.
+  end function
+
+  ! V-cycles to tolerance as iterative refinement: r = rhs - L u in fp64 (stored fp32), one V-cycle
+  ! on L e = r from e = 0 with level 1 in fp32 and levels >= 2 as always, u += e in fp64 - the
+  ! update, the next residual and max|e| (= the reference's max|u_new - u_old|, update_u
+  ! ndsm_multigrid_core.f90:1077-1122) are one pass.  e / its ping-pong partner live in the
+  ! memory of the fp64 path's ualt, r and the e-equation's residual in its r, u' in its prev.
+  function mg_solve_mixed(s, vc_tol, nmax, du_last, ncycles, ierr, hist) result(rc)
+    type(mg_solver), intent(inout) :: s
+    real(wp), intent(in) :: vc_tol
+    integer, intent(in) :: nmax
+    real(wp), intent(out) :: du_last
+    integer, intent(out) :: ncycles, ierr
+    real(wp), intent(inout), optional :: hist(:)
+    integer(c_int) :: rc
+    real(wp) :: met(2), du
+    integer :: it
+    integer(c_int) :: in_alt, force
+    integer(c_size_t) :: half
+    type(c_ptr) :: e, ealt, r32, rr32, tmp
+
+    du = huge(du); ncycles = 0; ierr = 1
+    du_last = du
+    half = int(s%npts1, c_size_t) * 4_c_size_t
+    e = s%dl(1)%ualt; ealt = dptr_offset(s%dl(1)%ualt, half)
+    ! s%r is also the residual scratch of the fp64 levels >= 2 (first 8 npts(2) <= 4 npts(1) bytes): the
+    ! e-equation's residual, dead once restricted, takes that half; its right-hand side the other
+    rr32 = s%r; r32 = dptr_offset(s%r, half)
+    force = merge(1_c_int, 0_c_int, s%precision == 2)
+    rc = ndsmk_fill0(e, half); if (rc /= 0) return
+    rc = ndsmk_update_residual_f32(s%lev(1)%g, s%dl(1)%u, c_null_ptr, rhs_of(s, 1), c_null_ptr, c_null_ptr, r32, met)
+    if (rc /= 0) return
+    do it = 1, nmax
+      ! ---- one V-cycle on the correction (fine_to_coarse / coarse_to_fine, :482-684) ----
+      rc = ndsmk_relax_f32(s%lev(1)%g, e, ealt, r32, int(s%ms, c_int), force, rr32, in_alt); if (rc /= 0) return
+      if (in_alt /= 0) then
+        tmp = e; e = ealt; ealt = tmp
+      end if
+      rc = ndsmk_restrict_f32(s%xf(1)%x, rr32, s%dl(2)%rhs, s%dl(2)%u); if (rc /= 0) return
+      rc = mg_vcycle_from(s, 2); if (rc /= 0) return
+      rc = mg_op(s, MG_OP_RELAX, 2, s%ms); if (rc /= 0) return
+      rc = ndsmk_prolong_add_f32(s%xf(1)%x, s%dl(2)%u, e); if (rc /= 0) return
+      rc = ndsmk_relax_f32(s%lev(1)%g, e, ealt, r32, int(s%ms, c_int), force, c_null_ptr, in_alt); if (rc /= 0) return
+      if (in_alt /= 0) then
+        tmp = e; e = ealt; ealt = tmp
+      end if
+      s%vcycles_done = s%vcycles_done + 1
+      ! ---- u' = u + e ; next residual ; max|e| ; the zeroed partner becomes the next e ----
+      rc = ndsmk_update_residual_f32(s%lev(1)%g, s%dl(1)%u, s%prev, rhs_of(s, 1), e, ealt, r32, met)
+      if (rc /= 0) return
+      tmp = s%dl(1)%u; s%dl(1)%u = s%prev; s%prev = tmp
+      tmp = e; e = ealt; ealt = tmp
       if (s%use_max) then
         du = met(1)
       else

@@ -24,7 +24,7 @@
 module ndsmh_vecpot
 
   use, intrinsic :: iso_c_binding
-  use, intrinsic :: iso_fortran_env, only: error_unit
+  use, intrinsic :: iso_fortran_env, only: error_unit, int64
   use ndsmh_iface
   use ndsmh_mg
   implicit none
@@ -32,7 +32,7 @@ module ndsmh_vecpot
 
   public :: vecpot_solve, poisson_solve
   public :: OPT_LEN, IOPT_MS, IOPT_NCYCLES, IOPT_FACE1, IOPT_IERR, IOPT_FLXCRL, IOPT_DEBUG, IOPT_DUMAX, &
-            IOPT_NMAXEX, IOPT_FAIL3D, IOPT_NGRIDS, IOPT_NCYC_OUT, ROPT_VTOL, ROPT_CTOL, ROPT_TIM, ROPT_DULAST
+            IOPT_NMAXEX, IOPT_FAIL3D, IOPT_NGRIDS, IOPT_NCYC_OUT, IOPT_PREC, ROPT_VTOL, ROPT_CTOL, ROPT_TIM, ROPT_DULAST
   public :: verbose
 
   ! option slots, 0-based like the reference (ndsm_vector_potential.f90:40-57)
@@ -43,6 +43,8 @@ module ndsmh_vecpot
   integer, parameter :: IOPT_FAIL3D = 8     ! out: bit c-1 set if 3-D solve c missed vc_tol
   integer, parameter :: IOPT_NGRIDS = 9     ! in : cap on the number of grid levels (0 = reference rule)
   integer, parameter :: IOPT_NCYC_OUT = 10  ! out: V-cycles used by the last 3-D solve that iterated
+  integer, parameter :: IOPT_PREC = 11      ! in : 0 fp64 throughout (reference arithmetic), 1 mixed precision for the
+                                            !      3-D solves (fp64 residual, fp32 correction V-cycle on level 1)
   integer, parameter :: ROPT_VTOL = 0, ROPT_CTOL = 1, ROPT_TIM = 2
   integer, parameter :: ROPT_DULAST = 3     ! out: du of the last V-cycle of the last 3-D solve
 
@@ -64,8 +66,27 @@ module ndsmh_vecpot
 
 contains
 
+  ! debug trace in the reference's format, plus (NDSM_HIP_TIMING set) the wall time since the
+  ! previous message - the device is drained first, so the figure belongs to the finished phase
   subroutine say(where, what)
     character(len=*), intent(in) :: where, what
+    integer(int64) :: c, r
+    real(wp) :: t
+    integer :: st, rc
+    logical, save :: first = .true., timing = .false.
+    real(wp), save :: t_last = 0
+    if (first) then
+      call get_environment_variable("NDSM_HIP_TIMING", status=st)
+      timing = (st == 0)
+      first = .false.
+    end if
+    if (timing) then
+      rc = ndsmk_sync()
+      call system_clock(c, r)
+      t = real(c, wp) / real(r, wp)
+      write (error_unit, '(A,F9.3,A)') "TIMING(+", t - t_last, " s) before: "//what
+      t_last = t
+    end if
     if (verbose) write (error_unit, '(A)') "DEBUG("//where//"):"//what
   end subroutine
 
@@ -75,8 +96,9 @@ contains
   ! h_rhs = c_null_ptr means rhs == 0.
   ! ------------------------------------------------------------------
   function poisson_solve(ndim, nshape, qx, qy, qz, bcs, ms, ex_tol, use_max, nmax_exact, ngrids_req, &
-                         vc_tol, nmax, h_u, h_rhs, du_last, ncycles, ierr, hist) result(rc)
+                         vc_tol, nmax, h_u, h_rhs, du_last, ncycles, ierr, hist, precision) result(rc)
     integer, intent(in) :: ndim, ms, nmax_exact, ngrids_req, nmax
+    integer, intent(in), optional :: precision
     integer(c_int32_t), intent(in) :: nshape(3)
     real(wp), intent(in) :: qx(:), qy(:), qz(:)
     character(len=1), intent(in) :: bcs(:)
@@ -94,6 +116,7 @@ contains
     rc = mg_create(s, ndim, nshape, qx, qy, qz, bcs, ngrids_req)
     if (rc == 0) then
       s%ms = ms; s%ex_tol = ex_tol; s%use_max = use_max; s%nmax_exact = nmax_exact
+      if (present(precision)) s%precision = precision
       rc = mg_set_u(s, h_u)
     end if
     if (rc == 0) then
@@ -219,6 +242,7 @@ contains
     rc = mg_create(s3, 3, n3, qx, qy, qz, bc3, ngr); live3 = .true.
     if (rc /= 0) goto 900
     s3%ex_tol = ropt(ROPT_CTOL); s3%use_max = use_max; s3%nmax_exact = int(iopt(IOPT_NMAXEX))
+    s3%precision = int(iopt(IOPT_PREC))
     rc = mg_zero_rhs(s3); if (rc /= 0) goto 900               ! :640-641 rhs = 0
     do c = 1, 3
       comp => A(:, :, :, c)

@@ -30,9 +30,12 @@ def get_lib_path(libname):
 
 
 def vector_potential(x, y, z, b, niterex_max=10000, ncycles_max=1024, ex_tol=1e-13, vc_tol=1e-10, ms=5, mean=False,
-                     libname=None, libpath=None, debug=False):
+                     libname=None, libpath=None, debug=False, mixed_precision=False):
     """Vector potential A and B = curl A of the current-free field whose normal
     component on the six box faces is taken from `b` (3,nz,ny,nx).
+
+    mixed_precision (additive; the reference has no such option): run the three 3-D solves as
+    fp64 residual + fp32 correction V-cycle (option slot get_iopt_prec(), BASELINE config[4]).
 
     Returns (ierr, A, B) with A, B shaped (3,nz,ny,nx); ierr != 0 flags a V-cycle
     iteration that did not reach vc_tol (codes >= 9001: device/runtime error).
@@ -76,6 +79,8 @@ def vector_potential(x, y, z, b, niterex_max=10000, ncycles_max=1024, ex_tol=1e-
     ropt[slots["ctol"]] = ex_tol
     ioptc[slots["debug"]] = lib.get_iopt_true() if debug else lib.get_iopt_false()
     ioptc[slots["dumax"]] = lib.get_iopt_false() if mean else lib.get_iopt_true()
+    if mixed_precision:
+        ioptc[lib.get_iopt_prec()] = 1
 
     apot = np.zeros(b.size, dtype=np.float64)
     bflat = b.flatten()

@@ -436,3 +436,33 @@ def test_reference_quirks(hip, port):
     ierr, A, B = ndsm_amd.vector_potential(x, y, z, b1.copy(), ms=3)
     ierr_o, A_o, B_o, _, _ = port.vector_potential(x, y, z, b1, ms=3)
     assert ierr == ierr_o and np.abs(A - A_o).max() <= 1e-11 * np.abs(A_o).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns", ([64, 64, 64], [128, 96, 80], [256, 256, 256]), ids=_tag)
+def test_mixed_precision_solve(hip, ns):
+    """BASELINE config[4] mode: fp64 residual + fp32 correction V-cycle on level 1 (csrc/mixed.hip).
+    In exact arithmetic it is the reference's iteration, so: the same number of V-cycles to the same
+    vc_tol, du history equal to fp32 rounding, and a final solution within a few vc_tol (the
+    stopping rule's own resolution; absolute, as vc_tol is) of the all-fp64 solve."""
+    mesh = uniform_mesh(ns)
+    for bcs in ("NDDNDD", "DNDDND", "DDDDDD"):
+        us, rhs = manufactured_poisson(mesh, bcs) if bcs == "NDDNDD" else (None, rand_field(tuple(ns[::-1]), 77) * 10.0)
+        u0 = np.zeros(tuple(ns[::-1]))
+        if us is not None:
+            u0[:, 0, :], u0[:, -1, :], u0[0], u0[-1] = us[:, 0, :], us[:, -1, :], us[0], us[-1]
+        S = hip.MGSolver(ns, mesh, bcs)
+        S.upload(1, hip.BUF_RHS, rhs)
+        S.upload(1, hip.BUF_U, u0)
+        ie64, du64, nc64, h64 = S.solve(vc_tol=1e-11, nmax=64, hist_len=64)
+        u64 = S.download(1, hip.BUF_U)
+        assert S.set_precision(2), "fp32 kernels should cover this level"
+        S.upload(1, hip.BUF_U, u0)
+        ie32, du32, nc32, h32 = S.solve(vc_tol=1e-11, nmax=64, hist_len=64)
+        u32 = S.download(1, hip.BUF_U)
+        S.close()
+        assert ie64 == 0 and ie32 == 0, (bcs, ie64, ie32)
+        assert abs(nc32 - nc64) <= 1, (bcs, nc32, nc64)
+        n = min(nc32, nc64) - 1
+        assert np.allclose(h32[:n], h64[:n], rtol=1e-3, atol=0), (bcs, h32[:n], h64[:n])
+        assert np.abs(u32 - u64).max() <= 5e-11, (bcs, np.abs(u32 - u64).max(), np.abs(u64).max())
