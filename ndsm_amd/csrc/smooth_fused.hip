@@ -95,7 +95,7 @@ struct Slot {
     live = p < NPX * TYH;
     in = live && i >= 0 && i + 1 < nx && j >= 0 && j < ny;
     own = in && li >= HX && li < TXH - HX && lj >= HY && lj < TYH - HY;
-    lo = live ? li + TXH * lj : 0;
+    lo = live ? p : 0;  // pair number = index inside each half of an LDS plane
   }
 };
 
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
                                                          ndsmk_grid g, FusedPlan pl) {
   using d2 = P2<T>;
   constexpr int SZ = (int)sizeof(T);
+  constexpr bool DEFER = !RES;
   const T gw0 = (T)g.w[0], gw1 = (T)g.w[1], gw2 = (T)g.w[2], gw1i = (T)g.w1, gwc = (T)g.wc;
   constexpr int NST = 2 * S;                 // smoothing stages
   constexpr int NSTG = RES ? NST + 1 : NST;  // pipeline depth = LDS planes = halo width
@@ -142,6 +143,11 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   constexpr int HX = (NSTG + 1) & ~1;        // x halo: even, pairs stay 16-byte aligned
   constexpr int TXI = TXH - 2 * HX, TYI = TYH - 2 * NSTG;
   constexpr int PLANE = TXH * TYH;
+  // An LDS plane is stored element-planar: first the element 0 of every pair, then every
+  // element 1.  A stage touches ONE element of each pair, so consecutive lanes then read
+  // consecutive words - with interleaved pairs every access had a 2-way bank conflict (42 % of
+  // the LDS cycles, SQ_LDS_BANK_CONFLICT).
+  constexpr int HALF = NPAIR * SZ;
   constexpr int BIG = 1 << 20;
   using SlotT = Slot<TXH, TYH, NT, HX, NSTG>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   // The loop body is issue bound, not bandwidth bound: everything that does not
   // depend on k is computed once and kept in registers (NS <= 2 slots per thread).
   struct SC {
-    int lo;        // pair's first element
+    int lo;        // the pair's slot in the first half of a plane (element 0); element 1 is HALF further
     int yl, yh;    // signed row deltas to the y neighbours (mirrored at the physical faces; 0 where
                    // the neighbour row is outside the tile - such rows are never updated)
     int xlo, xhi;  // outer x neighbour of element 0 / 1 (the pair partner where mirrored; always a
@@ -231,8 +237,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     c.go = q.i + nx * q.j;
     // rows whose y neighbours fall outside the loaded tile can never be updated: ring 0
     const bool yok = q.lj + (q.j == 0 ? 1 : -1) >= 0 && q.lj + (q.j == ny - 1 ? -1 : 1) < TYH;
-    c.yl = !yok ? 0 : ((q.j == 0) ? SZ * TXH : -SZ * TXH);
-    c.yh = !yok ? 0 : ((q.j == ny - 1) ? -SZ * TXH : SZ * TXH);
+    c.yl = !yok ? 0 : ((q.j == 0) ? SZ * NPX : -SZ * NPX);
+    c.yh = !yok ? 0 : ((q.j == ny - 1) ? -SZ * NPX : SZ * NPX);
     const bool yin = q.j >= g.lb[1] && q.j <= g.ub[1];
     const bool in0 = yin && q.i >= g.lb[0] && q.i <= g.ub[0];
     const bool in1 = yin && q.i + 1 >= g.lb[0] && q.i + 1 <= g.ub[0];
@@ -246,8 +252,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     if (!yok || !q.in) r0 = r1 = 0;
     if (!in0) r0 = 0;
     if (!in1) r1 = 0;
-    c.xlo = mir0 ? c.lo + SZ : (q.li - 1 >= 0 ? c.lo - SZ : c.lo);
-    c.xhi = mir1 ? c.lo : (q.li + 2 < TXH ? c.lo + 2 * SZ : c.lo + SZ);
+    c.xlo = mir0 ? c.lo + HALF : (q.li - 1 >= 0 ? c.lo + HALF - SZ : c.lo);
+    c.xhi = mir1 ? c.lo : (q.li + 2 < TXH ? c.lo + SZ : c.lo + HALF);
     int fl = (q.in ? 1 : 0) | (q.own ? 2 : 0) | (in0 ? 4 : 0) | (in1 ? 8 : 0);
     fl |= ((q.i + q.j + g.k0 + fp) & 1) ? 64 : 0;
     fl |= min(r0, 15) << 8;
@@ -278,7 +284,10 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const SlotT q(tid, s, x0, y0, nx, ny);
-      if (q.live) st2(B0 + q.lo, c0[s]);
+      if (q.live) {
+        B0[q.lo] = c0[s].x;
+        B0[NPAIR + q.lo] = c0[s].y;
+      }
     }
   }
   __syncthreads();
@@ -320,8 +329,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       const SC c = scs[s];
       const int e = ((c.fl >> 6) + k) & 1;
       ee[s] = e;
-      eB[s] = c.lo + SZ * e;      // the element, its pair partner, its outer x neighbour
-      oB[s] = c.lo + SZ - SZ * e;
+      eB[s] = c.lo + HALF * e;      // the element, its pair partner, its outer x neighbour
+      oB[s] = c.lo + HALF - HALF * e;
       xB[s] = e ? c.xhi : c.xlo;
       lim[s] = (c.fl >> (8 + 4 * e)) & 15;  // stage t may update it iff lim > t
       zplus[s] = pick(nxt[s], e);           // plane k+1, untouched by any stage yet
@@ -365,6 +374,12 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       }
     }
 
+    // Results of this iteration that go to HBM.  DEFER: they are STORED only after the window shift
+    // below has consumed the loads of plane k+2: vmcnt counts stores as well, and a store issued
+    // just before that wait would put its whole round trip on the critical path of every plane
+    // (measured: -5 % on the two-sweep launch; the sweep+residual launch is better off storing at once).
+    d2 finh[NS], resh[RES ? NS : 1];
+    bool fin_st[NS], res_st[RES ? NS : 1];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const SC c = scs[s];
@@ -374,21 +389,30 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       const int pf = k - (NST - 1);
       d2 fin;
       fin.x = fin.y = 0.0;
+      fin_st[s] = false;
       if (pf >= ks) {
-        fin = ld2(reinterpret_cast<const T *>(ldsb + bufoff(NST - 1) + c.lo));
-        if (pf >= zs && pf < ze && (fl & 2)) st2(uout + sz * (size_t)pf + c.go, fin);
+        fin.x = LDSD(bufoff(NST - 1) + c.lo);
+        fin.y = LDSD(bufoff(NST - 1) + c.lo + HALF);
+        fin_st[s] = pf >= zs && pf < ze && (fl & 2);
+        if (!DEFER && fin_st[s]) st2(uout + sz * (size_t)pf + c.go, fin);
         if (!RES) mLe[RES ? 0 : s] = pick(fin, 1 - ee[s]);
       }
+      finh[s] = fin;
       if (RES) {
         // residual of plane k-NST: centre f1, below f2, above fin (all final)
         const int pr = k - NST;
         const d2 cc = f1[RES ? s : 0], below = f2[RES ? s : 0];
-        if (pr >= zs && pr < ze && (fl & 2)) {
+        res_st[RES ? s : 0] = pr >= zs && pr < ze && (fl & 2);
+        resh[RES ? s : 0].x = resh[RES ? s : 0].y = 0.0;
+        if (res_st[RES ? s : 0]) {
           const int bR = bufoff(NST);
           const T xl0 = LDSD(bR + c.xlo);
           const T xh1 = LDSD(bR + c.xhi);
-          const d2 vl = ld2(reinterpret_cast<const T *>(ldsb + bR + c.lo + c.yl));
-          const d2 vh = ld2(reinterpret_cast<const T *>(ldsb + bR + c.lo + c.yh));
+          d2 vl, vh;
+          vl.x = LDSD(bR + c.lo + c.yl);
+          vl.y = LDSD(bR + c.lo + HALF + c.yl);
+          vh.x = LDSD(bR + c.lo + c.yh);
+          vh.y = LDSD(bR + c.lo + HALF + c.yh);
           const int prg = pr + g.k0;
           const d2 wl = (prg == 0) ? fin : below;
           const d2 wh = (prg == g.nzg - 1) ? below : fin;
@@ -401,7 +425,10 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
           d2 res;
           res.x = (inz && (fl & 4)) ? -v0 : (T)0;
           res.y = (inz && (fl & 8)) ? -v1 : (T)0;
-          st2(rout + sz * (size_t)pr + c.go, res);
+          if (DEFER)
+            resh[RES ? s : 0] = res;
+          else
+            st2(rout + sz * (size_t)pr + c.go, res);
         }
         f2[RES ? s : 0] = cc;
         f1[RES ? s : 0] = fin;
@@ -415,7 +442,10 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       char *bn = ldsb + bufoff(-1);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        if (k + 1 <= ke && tid0 + NT * s < NPAIR) st2(reinterpret_cast<T *>(bn + scs[s].lo), nxt[s]);
+        if (k + 1 <= ke && tid0 + NT * s < NPAIR) {
+          *reinterpret_cast<T *>(bn + scs[s].lo) = nxt[s].x;
+          *reinterpret_cast<T *>(bn + scs[s].lo + HALF) = nxt[s].y;
+        }
         nxt[s] = nn[s];
       }
       if (!RHS0) {
@@ -426,6 +456,18 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
           rw[s][0] = rn[s];
         }
       }
+    }
+    // ---- now the global stores: they have a whole iteration before the next vmcnt wait ----
+    // (the empty asm consumes the freshly loaded window HERE, so the wait for those loads is
+    // placed before the stores and cannot be sunk to the loop latch behind them)
+    if (DEFER) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(nxt[s].x), "v"(nxt[s].y) : "memory");
+    }
+#pragma unroll
+    for (int s = 0; s < (DEFER ? NS : 0); ++s) {
+      if (fin_st[s]) st2(uout + sz * (size_t)(k - (NST - 1)) + scs[s].go, finh[s]);
+      if (RES && res_st[RES ? s : 0]) st2(rout + sz * (size_t)(k - NST) + scs[s].go, resh[RES ? s : 0]);
     }
     kb = (kb + 1 == NSTG) ? 0 : kb + 1;
     __syncthreads();
