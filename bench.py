@@ -11,8 +11,9 @@ integration test, arrays resident in HBM before the timed region starts.
 
 value = fine-grid lattice-point updates per second over the WHOLE V-cycle:
         2*ms*nx*ny*nz smoother updates on level 1 per cycle / time per cycle
-        (coarse levels, residual, transfers and the metric are all inside the
-        timed region and count as overhead, not as updates).
+        (coarse levels, residual, transfers, the convergence metric of update_u
+        and the host's read-back of it are all inside the timed region and count
+        as overhead, not as updates).
 Extra keys: vcycles_per_s, smoother (kernel-only, HIP events), roofline of the
 dominant kernel (level-1 RB-GS sweep, 24 B/LUP algorithmic), cpu_baseline (the
 reference's own smoother timed on this box's host cores).
@@ -170,10 +171,13 @@ def main():
         S.upload(1, _lib.BUF_U, u0)
         S.zero_rhs()       # the vector potential's 3-D problems are Laplace problems (rhs = 0, :640-641)
         del u0
-        run_cycles = S.vcycle
+        # one step = one pass of the reference's solve loop (solve_poisson_bvp, ndsm_poisson.f90:104-150):
+        # V-cycle + update_u's max|u_new - u_old| + the host's strict du < vc_tol test; vc_tol = 0 is never
+        # met, so exactly K cycles run
+        run_cycles = lambda k: S.solve(vc_tol=0.0, nmax=k)  # noqa: E731
         ngrids = S.ngrids
-        workload = (f"{n}^3 vector-potential Ax component, one V-cycle per step (ms={ms}, {ngrids} grids), "
-                    "config[2] of BASELINE.json")
+        workload = (f"{n}^3 vector-potential Ax component, one V-cycle + convergence metric per step (ms={ms}, "
+                    f"{ngrids} grids), config[2] of BASELINE.json")
         parallelism = "single GPU"
         scaling = "weak"
     else:
@@ -201,10 +205,10 @@ def main():
         flag = torch.tensor([1.0 if S is not None else 0.0], dtype=torch.float64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if float(flag[0]) > 0.5:
-            run_cycles = S.vcycle
+            run_cycles = lambda k: S.solve(vc_tol=0.0, nmax=k)  # noqa: E731
             ngrids = 8
-            workload = (f"1024x1024x512 Poisson (Ax boundary data), one V-cycle per step (ms={ms}), "
-                        "config[3] of BASELINE.json")
+            workload = (f"1024x1024x512 Poisson (Ax boundary data), one V-cycle + convergence metric per step "
+                        f"(ms={ms}), config[3] of BASELINE.json")
             parallelism = (f"level 1 in {world} z-slabs (RCCL send/recv halo: 4 planes per neighbour per two-sweep "
                            "pass), levels>=2 on rank 0")
             scaling = "strong"
@@ -224,9 +228,9 @@ def main():
             S.upload(1, _lib.BUF_U, u0)
             S.zero_rhs()
             del u0
-            run_cycles = S.vcycle
+            run_cycles = lambda k: S.solve(vc_tol=0.0, nmax=k)  # noqa: E731
             ngrids = S.ngrids
-            workload = f"{n}^3 vector-potential Ax component per GPU, one V-cycle per step (ms={ms})"
+            workload = f"{n}^3 vector-potential Ax component per GPU, one V-cycle + convergence metric per step (ms={ms})"
             parallelism = f"{world} independent replicas (no exchange) - z-slab RCCL path failed to start"
             scaling = "weak"
             slab_mode = False
@@ -250,7 +254,11 @@ def main():
 
     # ---- dominant kernel: level-1 smoother sweeps under HIP events ---------
     nsw = 20
+    vc_only_ms = None
     if world == 1:
+        S.vcycle(2)
+        S.sync()
+        vc_only_ms = S.timed(lambda: S.vcycle(args.steps)) / args.steps   # the cycle without update_u
         # Laplace variant first (what the V-cycles above ran: rhs never read, 16 B/LUP algorithmic) ...
         S.op(_lib.OP_RELAX, 1, 2)
         S.sync()
@@ -312,6 +320,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": workload, "global_points": int(npts), "parallelism": parallelism},
         "vcycles_per_s": 1.0 / (ms_per_step * 1e-3),
+        "vcycle_without_metric_ms": vc_only_ms,
         "smoother": {"ms_per_sweep": sm_ms, "LUPs_per_s": npts / (sm_ms * 1e-3), "residual_ms": rs_ms,
                      "laplace_variant_ms_per_sweep": lap_ms,
                      "laplace_variant_LUPs_per_s": (npts / (lap_ms * 1e-3)) if lap_ms else None},

@@ -137,6 +137,14 @@ int ndsmk_balance_curl(double *A, double *B, const int32_t *n3, const double *x,
                        const double *z, const double *h_phi6, const double *h_span3,
                        const double *h_dq3, int curl_first);
 
+/* level-1 form for the V-cycle driver: three buffers (u on entry + two spares), `keep` (one of them
+ * or NULL) is never written, *where = 0/1/2 names the buffer holding the result.  r: residual of the
+ * result (may be NULL).  prev: have the launch of the last sweep evaluate max / sum |u_new - prev|
+ * (*met_done = 1 if it did; ndsmk_fetch_fused_metric reads the pair, blocking). */
+int ndsmk_relax3(const ndsmk_grid *g, double *u, double *a, double *b, const double *keep, const double *rhs,
+                 int nsweeps, double *r, const double *prev, int *where, int *met_done);
+int ndsmk_fetch_fused_metric(double *h_out2);
+
 /* ---- mixed-precision mode (mixed.hip): level 1 as iterative refinement, correction in fp32 ---- */
 /* unew = u + e ; ezero = 0 ; r = (float)(rhs - L unew) ; h_out2 = (max|e|, sum|e|), blocking.
  * e == NULL: r = residual of u, nothing else written.  rhs == NULL: zero right-hand side. */

@@ -15,7 +15,8 @@
 
 namespace ndsm {
 int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
-                       bool force, int *sweeps_done, double *rout, int *res_done);
+                       bool force, int *sweeps_done, double *rout, int *res_done, const double *prev, int *met_done);
+int fetch_fused_metric(double *h_out2);
 int launch_mean_shift(double *u, int64_t n);
 }
 
@@ -114,10 +115,16 @@ __global__ __launch_bounds__(256) void rbgs2_color(double *__restrict__ u, const
 
 }  // namespace
 
-static int relax_impl(const ndsmk_grid *gp, double *u, double *ualt, const double *rhs, int nsweeps, int variant,
-                      int *result_in_alt, double *rout, int *res_done) {
+// The sweeps of one relax call.  bufs[0] holds u on entry; the out-of-place fused passes write to
+// whichever of bufs[0..2] is neither the current one nor `keep` (bufs[2] may be null: plain
+// ping-pong); *where tells which buffer holds the result.  keep: a buffer that must survive (the
+// iterate the V-cycle started from, which the convergence metric is taken against); prev: evaluate
+// that metric in the launch of the last sweep (*met_done).  rout: residual on the last sweep.
+static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double *keep, const double *rhs, int nsweeps,
+                      int variant, int *where, double *rout, int *res_done, const double *prev, int *met_done) {
   NDSM_REQUIRE_READY();
   if (res_done) *res_done = 0;
+  if (met_done) *met_done = 0;
   const ndsmk_grid g = *gp;
   NDSM_CHECK_ARG(g.ndim == 2 || g.ndim == 3);
   NDSM_CHECK_ARG(g.n[0] >= 2 && g.n[1] >= 2 && (g.ndim == 2 ? g.n[2] == 1 : g.n[2] >= 2));
@@ -127,32 +134,43 @@ static int relax_impl(const ndsmk_grid *gp, double *u, double *ualt, const doubl
   const int64_t npts = (int64_t)g.n[0] * g.n[1] * g.n[2];
   hipStream_t s = ndsm::stream();
   const int mx = g.ub[0] - g.lb[0] + 1, my = g.ub[1] - g.lb[1] + 1, mz = g.ub[2] - g.lb[2] + 1;
+  int cur = 0;
+  if (where) *where = 0;
   if (mx <= 0 || my <= 0 || (g.ndim == 3 && mz <= 0)) return 0;  // nothing to update
-  double *const u_entry = u;
-  if (result_in_alt) *result_in_alt = 0;
+  // an in-place kernel may not touch the buffer the caller wants kept
+  auto in_place_ok = [&]() { return keep == nullptr || bufs[cur] != keep; };
   // small 3-D level: every sweep in one single-workgroup launch
   if (g.ndim == 3 && variant == 0 && !g.all_neumann && npts <= 4096 && g.k0 == 0 && g.zown0 == 0 &&
       g.zown1 == g.n[2] && nsweeps > 0) {
-    hipLaunchKernelGGL(rbgs3_small, dim3(1), dim3(1024), 0, s, u, rhs, g, nsweeps);
+    NDSM_CHECK_ARG(in_place_ok());
+    hipLaunchKernelGGL(rbgs3_small, dim3(1), dim3(1024), 0, s, bufs[0], rhs, g, nsweeps);
     NDSM_LAUNCH_CHECK();
     return 0;
   }
   for (int sw = 0; sw < nsweeps; ++sw) {
+    double *u = bufs[cur];
     if (g.ndim == 3) {
       bool done = false;
       if (variant != 1) {
+        // destination of an out-of-place pass: not the current buffer, not the kept one
+        int dst = -1;
+        for (int c = 0; c < 3; ++c)
+          if (c != cur && bufs[c] && bufs[c] != keep) {
+            dst = c;
+            break;
+          }
         // all-Neumann levels shift the mean after EVERY sweep: one sweep per pass there
         int ndone = 0;
         // the residual rides on the last sweep (not on all-Neumann levels: the mean shift comes in between)
-        int rc = ndsm::launch_rbgs3_fused(g, u, ualt, rhs, g.all_neumann ? 1 : nsweeps - sw, variant == 2, &ndone,
-                                          g.all_neumann ? nullptr : rout, res_done);
+        int rc = ndsm::launch_rbgs3_fused(g, u, dst >= 0 ? bufs[dst] : nullptr, rhs, g.all_neumann ? 1 : nsweeps - sw,
+                                          variant == 2, &ndone, g.all_neumann ? nullptr : rout, res_done,
+                                          g.all_neumann ? nullptr : prev, met_done);
         if (rc) return rc;
         done = ndone > 0;
         if (done) {  // the sweeps landed in the other array
           sw += ndone - 1;
-          double *t = u;
-          u = ualt;
-          ualt = t;
+          cur = dst;
+          u = bufs[cur];
         }
         if (!done && variant == 2)
           return ndsm::fail(NDSMK_EARG, "fused smoother does not support this level shape", __FILE__, __LINE__);
@@ -161,6 +179,7 @@ static int relax_impl(const ndsmk_grid *gp, double *u, double *ualt, const doubl
         if (g.zown0 != 0 || g.zown1 != g.n[2])
           return ndsm::fail(NDSMK_EARG, "z-slab levels need the fused smoother (nx even, >= 16 x 16 x 8 owned)", __FILE__,
                             __LINE__);
+        NDSM_CHECK_ARG(in_place_ok());
         const int half = (mx + 1) / 2;
         dim3 block(64, 4, 1);
         dim3 grid((half + 63) / 64, (my + 3) / 4, mz);
@@ -170,6 +189,7 @@ static int relax_impl(const ndsmk_grid *gp, double *u, double *ualt, const doubl
         }
       }
     } else {
+      NDSM_CHECK_ARG(in_place_ok());
       const int half = (mx + 1) / 2;
       dim3 block(64, 4, 1);
       dim3 grid((half + 63) / 64, (my + 3) / 4, 1);
@@ -183,11 +203,11 @@ static int relax_impl(const ndsmk_grid *gp, double *u, double *ualt, const doubl
       if (rc) return rc;
     }
   }
-  if (u != u_entry) {
-    if (result_in_alt) {
-      *result_in_alt = 1;
+  if (cur != 0) {
+    if (where) {
+      *where = cur;
     } else {  // caller cannot swap: bring the result home
-      NDSM_HIP(hipMemcpyAsync(u_entry, u, sizeof(double) * (size_t)npts, hipMemcpyDeviceToDevice, s));
+      NDSM_HIP(hipMemcpyAsync(bufs[0], bufs[cur], sizeof(double) * (size_t)npts, hipMemcpyDeviceToDevice, s));
     }
   }
   return 0;
@@ -195,7 +215,8 @@ static int relax_impl(const ndsmk_grid *gp, double *u, double *ualt, const doubl
 
 extern "C" int ndsmk_relax(const ndsmk_grid *gp, double *u, double *ualt, const double *rhs, int nsweeps,
                            int variant, int *result_in_alt) {
-  return relax_impl(gp, u, ualt, rhs, nsweeps, variant, result_in_alt, nullptr, nullptr);
+  double *const bufs[3] = {u, ualt, nullptr};
+  return relax_impl(gp, bufs, nullptr, rhs, nsweeps, variant, result_in_alt, nullptr, nullptr, nullptr, nullptr);
 }
 
 // nsweeps sweeps followed by r = rhs - L u: where the fused kernel covers the level
@@ -205,7 +226,8 @@ extern "C" int ndsmk_relax_residual(const ndsmk_grid *gp, double *u, double *ual
                                     int nsweeps, int variant, int *result_in_alt) {
   NDSM_CHECK_ARG(r != nullptr && result_in_alt != nullptr && (variant == 0 || variant == 2));
   int res_done = 0;
-  int rc = relax_impl(gp, u, ualt, rhs, nsweeps, variant, result_in_alt, r, &res_done);
+  double *const bufs[3] = {u, ualt, nullptr};
+  int rc = relax_impl(gp, bufs, nullptr, rhs, nsweeps, variant, result_in_alt, r, &res_done, nullptr, nullptr);
   if (rc) return rc;
   if (!res_done) {
     if (variant == 2)
@@ -213,4 +235,26 @@ extern "C" int ndsmk_relax_residual(const ndsmk_grid *gp, double *u, double *ual
     rc = ndsmk_residual(gp, *result_in_alt ? ualt : u, rhs, r);
   }
   return rc;
+}
+
+// The V-cycle driver's level-1 form of the two calls above: three buffers (u on entry, two
+// spares), `keep` is never written (the iterate the cycle started from), *where = 0/1/2 says
+// which buffer holds the result.  r != NULL: residual of the result (fused into the last sweep's
+// launch where possible).  prev != NULL: the launch of the last sweep also evaluates
+// max / sum |u_new - prev| (*met_done = 1; read it with ndsmk_fetch_fused_metric), if it can.
+extern "C" int ndsmk_relax3(const ndsmk_grid *gp, double *u, double *a, double *b, const double *keep,
+                            const double *rhs, int nsweeps, double *r, const double *prev, int *where,
+                            int *met_done) {
+  NDSM_CHECK_ARG(where != nullptr && met_done != nullptr && u && a);
+  int res_done = 0;
+  double *const bufs[3] = {u, a, b};
+  int rc = relax_impl(gp, bufs, keep, rhs, nsweeps, 0, where, r, &res_done, prev, met_done);
+  if (rc) return rc;
+  if (r && !res_done) rc = ndsmk_residual(gp, bufs[*where], rhs, r);
+  return rc;
+}
+
+extern "C" int ndsmk_fetch_fused_metric(double *h_out2) {
+  NDSM_REQUIRE_READY();
+  return ndsm::fetch_fused_metric(h_out2);
 }

@@ -127,11 +127,19 @@ struct Slot {
 // stage needs plane k-2S with its in-plane neighbours (one more LDS buffer) and
 // the thread's own pairs of planes k-2S+1 and k-2S-1 (registers); halo and chunk
 // warm-up grow by one.
-template <typename T, int S, int TXH, int TYH, int NT, int WPS, bool RHS0, bool RES>
+//
+// MODE 2 (MET): the launch that ends a V-cycle also evaluates the convergence metric of
+// update_u (ndsm_multigrid_core.f90:1077-1122), max and sum of |u_new - u_prev| over the points
+// it stores, against the iterate the cycle started from (prev; the V-cycle driver keeps that
+// buffer untouched) - per-workgroup partials, folded by fold_metric_k.  Replaces a separate
+// 24 B/pt pass (read u, read prev, write prev) by one more 8 B/pt read here.
+template <typename T, int S, int TXH, int TYH, int NT, int WPS, bool RHS0, int MODE>
 __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u, T *__restrict__ uout,
                                                          const T *__restrict__ rhs, T *__restrict__ rout,
+                                                         const T *__restrict__ prev, double *__restrict__ part,
                                                          ndsmk_grid g, FusedPlan pl) {
   using d2 = P2<T>;
+  constexpr bool RES = MODE == 1, MET = MODE == 2;
   constexpr int SZ = (int)sizeof(T);
   constexpr bool DEFER = !RES;
   const T gw0 = (T)g.w[0], gw1 = (T)g.w[1], gw2 = (T)g.w[2], gw1i = (T)g.w1, gwc = (T)g.wc;
@@ -156,7 +164,10 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   // ---- which (tile, chunk): consecutive y tiles share an XCD ---------
   const int nb8 = gridDim.x >> 3;
   const int w = (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3);
-  if (w >= pl.nwork) return;
+  if (w >= pl.nwork) {
+    if (MET && threadIdx.x == 0) part[2 * blockIdx.x] = part[2 * blockIdx.x + 1] = 0.0;
+    return;
+  }
   const int ty = w % pl.nty;
   const int t2 = w / pl.nty;
   const int tx = t2 % pl.ntx;
@@ -293,6 +304,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   __syncthreads();
 
   const int klast = ze + NSTG - 2;  // iteration in which the last stage reaches plane ze-1
+  double met_mx = 0.0, met_sm = 0.0;
   int kb = ks % NSTG;               // LDS buffer of plane k (RES: NSTG is not a power of two)
   for (int k = ks; k <= klast; ++k) {
     // byte offset of the LDS buffer of plane k - d, -1 <= d <= NSTG
@@ -319,6 +331,17 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 #pragma unroll
       for (int s = 0; s < (RHS0 ? 1 : NS); ++s)
         if (scs[s].fl & 1) rn[s] = ld2(pk + scs[s].go);
+    }
+
+    // MET: the previous iterate of the plane this iteration will store
+    d2 pvh[MET ? NS : 1];
+    if (MET) {
+      const int pf = k - (NST - 1);
+#pragma unroll
+      for (int s = 0; s < (MET ? NS : 1); ++s) {
+        pvh[s].x = pvh[s].y = 0.0;
+        if (pf >= zs && pf < ze && (scs[s].fl & 2)) pvh[s] = ld2(prev + sz * (size_t)pf + scs[s].go);
+      }
     }
 
     // ---- this iteration's element of every pair (the same for all stages) ----
@@ -466,18 +489,91 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     }
 #pragma unroll
     for (int s = 0; s < (DEFER ? NS : 0); ++s) {
+      if (MET && fin_st[s]) {
+        const double d0 = fabs((double)finh[s].x - (double)pvh[MET ? s : 0].x);
+        const double d1 = fabs((double)finh[s].y - (double)pvh[MET ? s : 0].y);
+        met_mx = fmax(met_mx, fmax(d0, d1));
+        met_sm = met_sm + d0;
+        met_sm = met_sm + d1;
+      }
       if (fin_st[s]) st2(uout + sz * (size_t)(k - (NST - 1)) + scs[s].go, finh[s]);
       if (RES && res_st[RES ? s : 0]) st2(rout + sz * (size_t)(k - NST) + scs[s].go, resh[RES ? s : 0]);
     }
     kb = (kb + 1 == NSTG) ? 0 : kb + 1;
     __syncthreads();
   }
+  if (MET) {
+    __shared__ double smx[NT / 64], ssm[NT / 64];
+    for (int o = 32; o > 0; o >>= 1) {
+      met_mx = fmax(met_mx, __shfl_down(met_mx, o, 64));
+      met_sm = met_sm + __shfl_down(met_sm, o, 64);
+    }
+    if ((tid0 & 63) == 0) {
+      smx[tid0 >> 6] = met_mx;
+      ssm[tid0 >> 6] = met_sm;
+    }
+    __syncthreads();
+    if (tid0 == 0) {
+      double m = smx[0], a = ssm[0];
+      for (int q = 1; q < NT / 64; ++q) {
+        m = fmax(m, smx[q]);
+        a = a + ssm[q];
+      }
+      part[2 * blockIdx.x] = m;
+      part[2 * blockIdx.x + 1] = a;
+    }
+  }
 #undef LDSD
 #undef NDSM_LOAD_PLANE
 }
 
-template <typename T, int S, int TXH, int TYH, int NT, int WPS, bool RES = false>
-int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int target_wgs, T *rout = nullptr) {
+// folds the per-workgroup (max, sum) partials of a MET launch in index order
+__global__ __launch_bounds__(256) void fold_metric_k(const double *__restrict__ part, int nblocks,
+                                                     double *__restrict__ out2) {
+  __shared__ double smx[4], ssm[4];
+  double mx = 0.0, sm = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+    mx = fmax(mx, part[2 * i]);
+    sm = sm + part[2 * i + 1];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = fmax(mx, __shfl_down(mx, o, 64));
+    sm = sm + __shfl_down(sm, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smx[threadIdx.x >> 6] = mx;
+    ssm[threadIdx.x >> 6] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out2[0] = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
+    out2[1] = ((ssm[0] + ssm[1]) + ssm[2]) + ssm[3];
+  }
+}
+
+// scratch of the metric partials (2 doubles per workgroup + the folded pair at the end)
+struct MetScratch {
+  double *d = nullptr;
+  size_t cap = 0;
+};
+MetScratch g_met;
+int met_scratch(size_t nblk, double **part, double **out2) {
+  if (nblk > g_met.cap) {
+    if (g_met.d) (void)hipFree(g_met.d);
+    g_met.d = nullptr;
+    g_met.cap = 0;
+    NDSM_HIP(hipMalloc((void **)&g_met.d, sizeof(double) * (2 * nblk + 2)));
+    g_met.cap = nblk;
+  }
+  *part = g_met.d;
+  *out2 = g_met.d + 2 * g_met.cap;
+  return 0;
+}
+
+template <typename T, int S, int TXH, int TYH, int NT, int WPS, int MODE = 0>
+int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int target_wgs, T *rout = nullptr,
+               const T *prev = nullptr) {
+  constexpr bool RES = MODE == 1;
   constexpr int NST = RES ? 2 * S + 1 : 2 * S;
   constexpr int TXI = TXH - 2 * ((NST + 1) & ~1), TYI = TYH - 2 * NST;
   static_assert(TXI > 0 && TYI > 0 && (TXH % 2) == 0, "tile");
@@ -490,16 +586,16 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
   static bool attr_set[2] = {false, false};
   static int wgs_per_cu[2] = {1, 1};
   const int v = rhs ? 0 : 1;
-  const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, RES>)
-                         : reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, RES>);
+  const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE>)
+                         : reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE>);
   if (!attr_set[v]) {
     NDSM_HIP(hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int occ = 1;
     if (rhs)
-      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, RES>, NT,
+      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE>, NT,
                                                             lds_bytes));
     else
-      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, RES>, NT,
+      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE>, NT,
                                                             lds_bytes));
     wgs_per_cu[v] = occ > 0 ? occ : 1;
     attr_set[v] = true;
@@ -533,15 +629,23 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
   pl.nzc = (nzo + pl.zc - 1) / pl.zc;
   pl.nwork = tiles * pl.nzc;
   const int nblk = ((pl.nwork + 7) / 8) * 8;
+  double *part = nullptr, *out2 = nullptr;
+  if (MODE == 2) {
+    if (int rc = met_scratch((size_t)nblk, &part, &out2)) return rc;
+  }
   if (rhs)
-    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, RES>), dim3(nblk), dim3(NT), lds_bytes,
-                       ndsm::stream(), u, uout, rhs, rout, g, pl);
+    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE>), dim3(nblk), dim3(NT), lds_bytes,
+                       ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl);
   else  // the level's rhs is identically zero (level 1 of NDSM's Laplace problems,
         // ndsm_vector_potential.f90:640-641): x - 0.0 == x exactly, so the variant that never
         // loads rhs returns the same bits with 8 B/LUP less traffic
-    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, RES>), dim3(nblk), dim3(NT), lds_bytes,
-                       ndsm::stream(), u, uout, rhs, rout, g, pl);
+    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE>), dim3(nblk), dim3(NT), lds_bytes,
+                       ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl);
   NDSM_LAUNCH_CHECK();
+  if (MODE == 2) {
+    hipLaunchKernelGGL(fold_metric_k, dim3(1), dim3(256), 0, ndsm::stream(), part, nblk, out2);
+    NDSM_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -570,9 +674,10 @@ static const int *fused_cfg() {
 // max_sweeps sweeps, i.e. when this call runs a single sweep with max_sweeps == 1.
 template <typename T>
 static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int max_sweeps, bool force,
-                          int *sweeps_done, T *rout, int *res_done) {
+                          int *sweeps_done, T *rout, int *res_done, const T *prev = nullptr, int *met_done = nullptr) {
   *sweeps_done = 0;
   if (res_done) *res_done = 0;
+  if (met_done) *met_done = 0;
   if (!uout || g.ndim != 3 || (g.n[0] & 1) || g.n[0] < 16 || g.n[1] < 16 || g.zown1 - g.zown0 < 8) return 0;
   // a z-streaming workgroup walks >= 16 planes serially: with fewer than ~one
   // workgroup per CU the sweep is latency bound and the two colour passes win
@@ -592,6 +697,28 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   // two sweeps per pass - not for the last two sweeps when the residual is wanted (it rides
   // on a one-sweep pass)
   const bool two = max_sweeps >= 2 && ghosts >= 4 && cfg[0] != 9 && !(res && max_sweeps == 2);
+  // prev != nullptr: the launch that performs the last of the max_sweeps sweeps also evaluates
+  // the convergence metric against prev (fp64, single domain; *met_done says it did)
+  const bool met = std::is_same<T, double>::value && prev && met_done && !slab;
+  if constexpr (std::is_same<T, double>::value) {
+    if (met && two && max_sweeps == 2) {
+      rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 2>(g, u, uout, rhs, tgt, nullptr, prev));
+      if (rc) return rc;
+      *sweeps_done = 2;
+      *met_done = 1;
+      return 0;
+    }
+    if (met && !two && max_sweeps == 1 && !res) {
+      if (big)
+        rc = (launch_cfg<T, 1, 132, 31, 1024, 4, 2>(g, u, uout, rhs, tgt, nullptr, prev));
+      else
+        rc = (launch_cfg<T, 1, 132, 23, 768, 4, 2>(g, u, uout, rhs, tgt, nullptr, prev));
+      if (rc) return rc;
+      *sweeps_done = 1;
+      *met_done = 1;
+      return 0;
+    }
+  }
   if (two) {
     switch (cfg[0]) {
       case 3: rc = launch_cfg<T, 2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;
@@ -604,8 +731,8 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   }
   if (res && max_sweeps == 1) {
     switch (cfg[2]) {
-      case 1: rc = (launch_cfg<T, 1, 136, 30, 1024, 4, true>(g, u, uout, rhs, tgt, rout)); break;
-      default: rc = (launch_cfg<T, 1, 136, 22, 768, 4, true>(g, u, uout, rhs, tgt, rout)); break;
+      case 1: rc = (launch_cfg<T, 1, 136, 30, 1024, 4, 1>(g, u, uout, rhs, tgt, rout)); break;
+      default: rc = (launch_cfg<T, 1, 136, 22, 768, 4, 1>(g, u, uout, rhs, tgt, rout)); break;
     }
     if (rc) return rc;
     *sweeps_done = 1;
@@ -622,8 +749,17 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
 }
 
 int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
-                       bool force, int *sweeps_done, double *rout, int *res_done) {
-  return launch_fused_t<double>(g, u, uout, rhs, max_sweeps, force, sweeps_done, rout, res_done);
+                       bool force, int *sweeps_done, double *rout, int *res_done, const double *prev,
+                       int *met_done) {
+  return launch_fused_t<double>(g, u, uout, rhs, max_sweeps, force, sweeps_done, rout, res_done, prev, met_done);
+}
+
+// (max, sum) of |u_new - u_prev| left on the device by the last MET launch -> host (blocking)
+int fetch_fused_metric(double *h_out2) {
+  if (!g_met.d) return fail(NDSMK_EARG, "no fused metric has been computed", __FILE__, __LINE__);
+  NDSM_HIP(hipMemcpyAsync(h_out2, g_met.d + 2 * g_met.cap, 2 * sizeof(double), hipMemcpyDeviceToHost, stream()));
+  NDSM_HIP(hipStreamSynchronize(stream()));
+  return 0;
 }
 
 // fp32 instantiation: the correction equation L e = r of the mixed-precision mode (same tiles:

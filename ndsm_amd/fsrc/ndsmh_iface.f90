@@ -135,6 +135,22 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_relax3(g, u, a, b, keep, rhs, nsweeps, r, prev, where, met_done) &
+        bind(c, name="ndsmk_relax3") result(rc)
+      import :: ndsmk_grid, c_ptr, c_int
+      type(ndsmk_grid), intent(in) :: g
+      type(c_ptr), value :: u, a, b, keep, rhs, r, prev
+      integer(c_int), value :: nsweeps
+      integer(c_int), intent(out) :: where, met_done
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_fetch_fused_metric(h_out2) bind(c, name="ndsmk_fetch_fused_metric") result(rc)
+      import :: c_int, c_double
+      real(c_double), intent(out) :: h_out2(2)
+      integer(c_int) :: rc
+    end function
+
     function ndsmk_update_residual_f32(g, u, unew, rhs, e, ezero, r, h_out2) &
         bind(c, name="ndsmk_update_residual_f32") result(rc)
       import :: ndsmk_grid, c_ptr, c_int, c_double

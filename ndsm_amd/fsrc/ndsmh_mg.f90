@@ -30,13 +30,15 @@ module ndsmh_mg
   public :: mg_mark_rhs_set
   public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
   public :: MG_BUF_U, MG_BUF_RHS, MG_BUF_R
+  public :: MG_OP_RELAX_LAST
   public :: MG_OP_RELAX, MG_OP_RESIDUAL, MG_OP_RESTRICT, MG_OP_PROLONG, MG_OP_EXACT, MG_OP_RELAX_COLOR, &
             MG_OP_RELAX_FUSED, MG_OP_RESREST, MG_OP_RELAX_RES, MG_OP_RELAX_RES_FUSED
 
   integer, parameter :: MG_BUF_U = 0, MG_BUF_RHS = 1, MG_BUF_R = 2
   integer, parameter :: MG_OP_RELAX = 0, MG_OP_RESIDUAL = 1, MG_OP_RESTRICT = 2, MG_OP_PROLONG = 3, &
                         MG_OP_EXACT = 4, MG_OP_RELAX_COLOR = 5, MG_OP_RELAX_FUSED = 6, &
-                        MG_OP_RESREST = 7, MG_OP_RELAX_RES = 8, MG_OP_RELAX_RES_FUSED = 9
+                        MG_OP_RESREST = 7, MG_OP_RELAX_RES = 8, MG_OP_RELAX_RES_FUSED = 9, &
+                        MG_OP_RELAX_LAST = 10   ! the sweeps that end a V-cycle (level 1)
 
   integer(c_size_t), parameter :: R8 = 8_c_size_t, I4 = 4_c_size_t
 
@@ -68,6 +70,12 @@ module ndsmh_mg
     integer(ik) :: npts1 = 0             ! elements of the level-1 device arrays (local window if z-slab)
     logical :: rhs1_zero = .false.        ! level-1 rhs is identically zero: kernels skip reading it
     logical :: allow_fused_rr = .false.  ! resrest.hip is correct but not yet faster than residual + streamed restriction
+    ! ---- convergence metric without a pass of its own (mg_solve, level 1 on the fused smoother):
+    ! the buffer holding the iterate a V-cycle starts from is kept untouched (u, ualt and prev
+    ! rotate), and the launch of the cycle's last sweep evaluates max / sum |u_new - u_start|
+    logical :: track = .false.           ! the V-cycle in progress runs in that mode
+    logical :: met_done = .false.        ! its last sweep did evaluate the metric
+    type(c_ptr) :: keep = c_null_ptr     ! the kept buffer
     integer :: precision = 0             ! 0 fp64 (reference arithmetic), 1 mixed where level 1 is large enough,
                                          ! 2 mixed wherever the fp32 kernels cover level 1 (tests)
     ! ---- z-slab mode (level 1 distributed, SURVEY 8e); unused otherwise
@@ -451,9 +459,13 @@ contains
     if (level < 1 .or. level > s%ngrids) return
     if (level >= 2 .and. .not. s%has_coarse) return
     if (s%slab .and. level == 1 .and. (op == MG_OP_RESTRICT .or. op == MG_OP_PROLONG)) return  ! mg_slab_* instead
+    if (level == 1 .and. s%track .and. (op == MG_OP_RELAX .or. op == MG_OP_RELAX_RES .or. op == MG_OP_RELAX_LAST)) then
+      rc = relax_tracked(s, int(count), op == MG_OP_RELAX_RES, op == MG_OP_RELAX_LAST)
+      return
+    end if
     select case (op)
-    case (MG_OP_RELAX, MG_OP_RELAX_COLOR, MG_OP_RELAX_FUSED)
-      variant = merge(0, merge(1, 2, op == MG_OP_RELAX_COLOR), op == MG_OP_RELAX)
+    case (MG_OP_RELAX, MG_OP_RELAX_COLOR, MG_OP_RELAX_FUSED, MG_OP_RELAX_LAST)
+      variant = merge(0, merge(1, 2, op == MG_OP_RELAX_COLOR), op == MG_OP_RELAX .or. op == MG_OP_RELAX_LAST)
       rc = ndsmk_relax(s%lev(level)%g, s%dl(level)%u, s%dl(level)%ualt, rhs_of(s, level), int(count, c_int), &
                        int(variant, c_int), swapped)
       if (rc == 0 .and. swapped /= 0) then      ! the swept field lives in the partner array now
@@ -486,6 +498,25 @@ contains
       rc = ndsmk_solve_exact(s%lev(level)%g, s%dl(level)%u, s%dl(level)%rhs, s%scr, s%ex_tol, &
                              merge(1_c_int, 0_c_int, s%use_max), int(s%nmax_exact, c_int), s%info)
     end select
+  end function
+
+  ! level-1 sweeps in track mode: three rotating buffers, s%keep is never written
+  function relax_tracked(s, nsweeps, with_res, last) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer, intent(in) :: nsweeps
+    logical, intent(in) :: with_res, last
+    integer(c_int) :: rc
+    integer(c_int) :: where, met
+    type(c_ptr) :: b(0:2), rr, pv
+    b(0) = s%dl(1)%u; b(1) = s%dl(1)%ualt; b(2) = s%prev
+    rr = c_null_ptr; if (with_res) rr = s%r
+    pv = c_null_ptr; if (last) pv = s%keep
+    rc = ndsmk_relax3(s%lev(1)%g, b(0), b(1), b(2), s%keep, rhs_of(s, 1), int(nsweeps, c_int), rr, pv, where, met)
+    if (rc /= 0) return
+    if (last) s%met_done = (met /= 0)
+    s%dl(1)%u = b(where)
+    s%dl(1)%ualt = b(mod(where + 1, 3))
+    s%prev = b(mod(where + 2, 3))
   end function
 
   ! ------------------------------------------------------------------
@@ -527,7 +558,7 @@ contains
     do l = s%ngrids, ltop + 1, -1
       rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
       rc = mg_op(s, MG_OP_PROLONG, l - 1, 1); if (rc /= 0) return
-      rc = mg_op(s, MG_OP_RELAX, l - 1, s%ms); if (rc /= 0) return
+      rc = mg_op(s, merge(MG_OP_RELAX_LAST, MG_OP_RELAX, l - 1 == 1), l - 1, s%ms); if (rc /= 0) return
     end do
     rc = 0
   end function
@@ -569,6 +600,7 @@ contains
     integer(c_int) :: rc
     real(wp) :: met(2), du
     integer :: it
+    logical :: trk
 
     if (mg_mixed_applies(s)) then
       rc = mg_solve_mixed(s, vc_tol, nmax, du_last, ncycles, ierr, hist)
@@ -577,11 +609,30 @@ contains
     du = huge(du)
     ncycles = 0
     ierr = 1
+    trk = mg_track_applies(s)
     ! the caller's array is the "previous iterate" of the first comparison (:122)
-    rc = ndsmk_d2d(s%prev, s%dl(1)%u, int(s%npts1, c_size_t) * R8); if (rc /= 0) return
+    if (.not. trk) then
+      rc = ndsmk_d2d(s%prev, s%dl(1)%u, int(s%npts1, c_size_t) * R8); if (rc /= 0) return
+    end if
     do it = 1, nmax
-      rc = mg_vcycle(s); if (rc /= 0) return
-      rc = ndsmk_diff_metrics(s%dl(1)%u, s%prev, s%npts1, 1_c_int, met); if (rc /= 0) return
+      if (trk) then
+        ! the buffer u sits in is the previous iterate: kept as it is, no copy, and the cycle's
+        ! last sweep takes the metric against it
+        s%track = .true.; s%met_done = .false.; s%keep = s%dl(1)%u
+        rc = mg_vcycle(s)
+        s%track = .false.
+        if (rc /= 0) return
+        if (s%met_done) then
+          rc = ndsmk_fetch_fused_metric(met)
+        else
+          rc = ndsmk_diff_metrics(s%dl(1)%u, s%keep, s%npts1, 0_c_int, met)
+        end if
+        s%keep = c_null_ptr
+        if (rc /= 0) return
+      else
+        rc = mg_vcycle(s); if (rc /= 0) return
+        rc = ndsmk_diff_metrics(s%dl(1)%u, s%prev, s%npts1, 1_c_int, met); if (rc /= 0) return
+      end if
       if (s%use_max) then
         du = met(1)
       else
@@ -603,6 +654,24 @@ contains
   ! ------------------------------------------------------------------
   ! Mixed-precision mode (BASELINE config[4]; csrc/mixed.hip has the algebra).
   ! ------------------------------------------------------------------
+  ! May mg_solve keep the start-of-cycle iterate in place and let the last sweep take the metric?
+  ! Level 1 must run on the out-of-place fused smoother for every sweep: 3-D, single domain, even
+  ! nx, above the size where relax falls back to the in-place colour passes.  (NDSM_HIP_NO_TRACK
+  ! set: never - A/B testing.)
+  function mg_track_applies(s) result(ok)
+    type(mg_solver), intent(in) :: s
+    logical :: ok
+    integer :: st
+    ok = .false.
+    if (s%ndim /= 3 .or. s%slab .or. s%ngrids < 2 .or. s%ms < 1) return
+    if (s%lev(1)%g%all_neumann /= 0) return
+    if (mod(s%lev(1)%n(1), 2) /= 0 .or. any(s%lev(1)%n(1:2) < 16) .or. s%lev(1)%n(3) < 8) return
+    if (s%lev(1)%npts < 6_ik * 1024_ik * 1024_ik) return
+    call get_environment_variable("NDSM_HIP_NO_TRACK", status=st)
+    if (st == 0) return
+    ok = .true.
+  end function
+
   ! Is the solve run as fp64 residual + fp32 correction V-cycle?  Asked for, 3-D, single domain,
   ! >= 2 grids, ms >= 1, and level 1 within reach of the fp32 kernels (fused smoother, streamed
   ! restriction, tiled prolongation); otherwise the fp64 path runs.

@@ -466,3 +466,36 @@ def test_mixed_precision_solve(hip, ns):
         n = min(nc32, nc64) - 1
         assert np.allclose(h32[:n], h64[:n], rtol=1e-3, atol=0), (bcs, h32[:n], h64[:n])
         assert np.abs(u32 - u64).max() <= 5e-11, (bcs, np.abs(u32 - u64).max(), np.abs(u64).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns,ms", (([256, 192, 160], 5), ([192, 192, 192], 4), ([256, 256, 256], 1)), ids=str)
+def test_fused_metric_bitwise(hip, ns, ms):
+    """mg_solve on a large level 1 keeps the start-of-cycle iterate in place (three rotating buffers)
+    and lets the launch of the cycle's last sweep evaluate update_u's max|u_new - u_old|
+    (ndsm_multigrid_core.f90:1077-1122): same du history, same cycle count and same solution bits as
+    the separate metric pass (NDSM_HIP_NO_TRACK), for ms odd, even and 1, general and declared-zero rhs."""
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u0, rhs = rand_field(shp, 11), rand_field(shp, 12) * 50.0
+    for bcs in ("NDDNDD", "DDNDDN"):
+        for laplace in (False, True):
+            out = []
+            for notrack in (True, False):
+                if notrack:
+                    os.environ["NDSM_HIP_NO_TRACK"] = "1"
+                else:
+                    os.environ.pop("NDSM_HIP_NO_TRACK", None)
+                S = hip.MGSolver(ns, mesh, bcs, ms=ms)
+                if laplace:
+                    S.zero_rhs()
+                else:
+                    S.upload(1, hip.BUF_RHS, rhs)
+                S.upload(1, hip.BUF_U, u0)
+                ie, du, nc, h = S.solve(vc_tol=1e-9, nmax=6, hist_len=16)
+                out.append((ie, du, nc, list(h), S.download(1, hip.BUF_U)))
+                S.close()
+            os.environ.pop("NDSM_HIP_NO_TRACK", None)
+            a, b = out
+            assert a[:4] == b[:4], (bcs, laplace, a[:4], b[:4])
+            assert np.array_equal(a[4], b[4]), (bcs, laplace)
