@@ -499,3 +499,46 @@ def test_fused_metric_bitwise(hip, ns, ms):
             a, b = out
             assert a[:4] == b[:4], (bcs, laplace, a[:4], b[:4])
             assert np.array_equal(a[4], b[4]), (bcs, laplace)
+
+
+@pytest.mark.gpu
+def test_pipeline_mixed_precision_and_large_paths(hip):
+    """The whole ndsm_vector_solve pipeline at a size where every large-level path is live (fused
+    two-sweep smoother, sweep+residual launch, streamed restriction, tiled prolongation, kept-iterate
+    metric): known-answer errors fall as h^2 against the analytic field (the reference's own
+    acceptance test, tests/integration_test/integration_test1.py), and the additive mixed-precision
+    option (get_iopt_prec) reproduces the fp64 pipeline to the solve tolerance."""
+    import ndsm_amd
+    n = 192
+    x, y, z, A1, b1 = analytic_case(n)
+    ierr, A, B = ndsm_amd.vector_potential(x, y, z, b1.copy())
+    assert ierr == 0
+    ea = np.linalg.norm(A1 - A, axis=0)
+    eb = np.linalg.norm(b1 - B, axis=0)
+    h = x[1] - x[0]
+    # results_test1.txt rows (22..220) scale as Ea_max ~ 0.9 h^2, Eb_max ~ 37 h^2
+    assert ea.max() < 2.0 * h * h and eb.max() < 60.0 * h * h, (ea.max() / h ** 2, eb.max() / h ** 2)
+    ierr2, A2, B2 = ndsm_amd.vector_potential(x, y, z, b1.copy(), mixed_precision=True)
+    assert ierr2 == 0
+    assert np.abs(A2 - A).max() <= 1e-9 * np.abs(A).max(), np.abs(A2 - A).max()
+    assert np.abs(B2 - B).max() <= 1e-9 * np.abs(A).max() * 4 / h, np.abs(B2 - B).max()
+
+
+@pytest.mark.gpu
+def test_slab_world_laplace_variant(hip):
+    """World.zero_rhs: the z-slab path with the rhs declared zero (kernels never read it) returns the
+    bits of the single-domain solver with a zero rhs uploaded"""
+    ns, nranks = [64, 64, 96], 3
+    mesh = uniform_mesh(ns)
+    u = rand_field(tuple(ns[::-1]), 5)
+    S = hip.MGSolver(ns, mesh, "DNDDND")
+    W = hip.World(ns, mesh, "DNDDND", nranks)
+    S.upload(1, hip.BUF_U, u)
+    S.upload(1, hip.BUF_RHS, np.zeros_like(u))
+    W.upload(hip.BUF_U, u)
+    W.zero_rhs()
+    S.vcycle(2)
+    W.vcycle(2)
+    assert np.array_equal(W.download(hip.BUF_U), S.download(1, hip.BUF_U))
+    S.close()
+    W.close()
