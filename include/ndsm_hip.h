@@ -160,6 +160,9 @@ int ndsm_hip_world_create(const int *nshape, const double *x, const double *y, c
                           int nranks, int rank, void **handle);
 int ndsm_hip_world_destroy(void *handle);
 int ndsm_hip_world_nlocal(void *handle);                          /* slabs held by this process */
+/* how many levels are distributed (1 = only the finest; more where a rank's share of the next level
+ * is still large: its restricted planes then never travel to rank 0; NDSM_HIP_DIST_LEVELS=k forces) */
+int ndsm_hip_world_dist_levels(void *handle);
 int ndsm_hip_world_slab(void *handle, int ilocal, int *info12);   /* its plan row */
 /* which: 0 = u, 1 = rhs, 2 = residual.  host holds nplanes whole x-y planes starting at GLOBAL
  * plane gz0; the planes that fall into slab ilocal's window (ghosts included) are copied. */

@@ -66,6 +66,7 @@ def load_library(path=None):
                                         ctypes.POINTER(ctypes.c_void_p)]
     L.ndsm_hip_world_destroy.argtypes = [ctypes.c_void_p]
     L.ndsm_hip_world_nlocal.argtypes = [ctypes.c_void_p]
+    L.ndsm_hip_world_dist_levels.argtypes = [ctypes.c_void_p]
     L.ndsm_hip_world_slab.argtypes = [ctypes.c_void_p, ctypes.c_int, _ip]
     L.ndsm_hip_world_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int]
     L.ndsm_hip_world_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
@@ -239,6 +240,7 @@ class World:
                                           int(nranks), int(rank), ctypes.byref(self.h))
         _check(rc, "ndsm_hip_world_create", self.L)
         self.nlocal = self.L.ndsm_hip_world_nlocal(self.h)
+        self.dist_levels = self.L.ndsm_hip_world_dist_levels(self.h)
         self.slabs = []
         for i in range(1, self.nlocal + 1):
             info = np.zeros(12, dtype=np.intc)

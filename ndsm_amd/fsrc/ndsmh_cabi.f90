@@ -569,10 +569,7 @@ contains
       deallocate (w)
       return
     end if
-    do i = 1, w%nlocal
-      w%loc(i)%ms = ms; w%loc(i)%ex_tol = ex_tol; w%loc(i)%use_max = (du_max == 1)
-      w%loc(i)%nmax_exact = nmax_exact
-    end do
+    call world_set_params(w, int(ms), ex_tol, du_max == 1, int(nmax_exact))
     handle = c_loc(w)
   end function
 
@@ -585,6 +582,14 @@ contains
     call c_f_pointer(handle, w)
     call world_destroy(w)
     deallocate (w)
+  end function
+
+  function ndsm_hip_world_dist_levels(handle) bind(c, name="ndsm_hip_world_dist_levels") result(n)
+    type(c_ptr), value :: handle
+    integer(c_int) :: n
+    type(mg_world), pointer :: w
+    call c_f_pointer(handle, w)
+    n = world_dist_levels(w)
   end function
 
   function ndsm_hip_world_nlocal(handle) bind(c, name="ndsm_hip_world_nlocal") result(n)

@@ -76,11 +76,16 @@ contains
   !   * ghost depth = max(2, deepest tap outside the owner's slab): 2 planes feed
   !     the fused smoother's red/black pipeline, the rest the restriction.
   ! ok = .false. if some slab would own fewer planes than the ghost depth.
-  subroutine plan_slabs(nz, nzc, tz, nranks, plan, ok)
+  ! part (optional): prescribed slab boundaries, rank r owns [part(r), part(r+1)) - used when this
+  ! level is itself the coarse level of a distributed finer one, whose restriction ownership
+  ! fixes the split; min_depth (optional): ghost planes the finer level's prolongation reads.
+  subroutine plan_slabs(nz, nzc, tz, nranks, plan, ok, part, min_depth)
     integer, intent(in) :: nz, nzc, nranks
     type(axis_xfer_t), intent(in) :: tz
     type(slab_t), allocatable, intent(out) :: plan(:)
     logical, intent(out) :: ok
+    integer, intent(in), optional :: part(0:)
+    integer, intent(in), optional :: min_depth
     integer :: r, kc, m, own, depth, lo, hi
 
     ok = .false.
@@ -88,11 +93,20 @@ contains
     allocate (plan(0:nranks - 1))
     do r = 0, nranks - 1
       plan(r)%rank = r; plan(r)%nranks = nranks
-      plan(r)%z0 = int((int(r, ik) * nz) / nranks)
-      plan(r)%z1 = int((int(r + 1, ik) * nz) / nranks)
+      if (present(part)) then
+        plan(r)%z0 = part(r); plan(r)%z1 = part(r + 1)
+        if (plan(r)%z1 <= plan(r)%z0) return
+      else
+        plan(r)%z0 = int((int(r, ik) * nz) / nranks)
+        plan(r)%z1 = int((int(r + 1, ik) * nz) / nranks)
+      end if
       plan(r)%ck0 = nzc; plan(r)%ck1 = 0
     end do
+    if (present(part)) then
+      if (part(0) /= 0 .or. part(nranks) /= nz) return
+    end if
     depth = 4      ! two sweeps per halo exchange: each sweep consumes two ghost planes per side
+    if (present(min_depth)) depth = max(depth, min_depth)
     do kc = 0, nzc - 1
       lo = tz%rlo(kc + 1); hi = lo + tz%rcnt(kc + 1)      ! fine taps [lo, hi)
       m = lo + tz%rcnt(kc + 1) / 2
@@ -150,11 +164,15 @@ contains
   end function
 
   ! Shapes and meshes of all levels; lev(1) is the caller's mesh verbatim.
-  subroutine build_levels(ndim, nshape, qx, qy, qz, ngrids, lev)
+  ! ext (optional, (2,3)): origin and extent per axis to use for the coarse meshes instead of those
+  ! of (qx,qy,qz) - a hierarchy that starts at level l of a larger one must repeat THAT one's
+  ! meshes bit for bit, and the end points of a coarse mesh are not exactly those of the finest.
+  subroutine build_levels(ndim, nshape, qx, qy, qz, ngrids, lev, ext)
     integer, intent(in) :: ndim, ngrids
     integer(c_int32_t), intent(in) :: nshape(3)
     real(wp), intent(in) :: qx(:), qy(:), qz(:)
     type(level_t), allocatable, intent(out) :: lev(:)
+    real(wp), intent(in), optional :: ext(2, 3)
     integer :: l, d, j, nq
     real(wp) :: qmin, span
 
@@ -174,6 +192,9 @@ contains
         nq = lev(l)%n(d)
         qmin = minval(lev(1)%ax(d)%q)
         span = maxval(lev(1)%ax(d)%q) - qmin
+        if (present(ext)) then
+          qmin = ext(1, d); span = ext(2, d)
+        end if
         allocate (lev(l)%ax(d)%q(nq))
         do j = 1, nq
           lev(l)%ax(d)%q(j) = (j - 1) * span / real(nq - 1, wp) + qmin

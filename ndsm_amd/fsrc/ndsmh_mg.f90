@@ -91,7 +91,7 @@ contains
   ! ------------------------------------------------------------------
   ! construction
   ! ------------------------------------------------------------------
-  function mg_create(s, ndim, nshape, qx, qy, qz, bcs, ngrids_req, slab) result(rc)
+  function mg_create(s, ndim, nshape, qx, qy, qz, bcs, ngrids_req, slab, coarse_here, ext) result(rc)
     type(mg_solver), intent(out) :: s
     integer, intent(in) :: ndim
     integer(c_int32_t), intent(in) :: nshape(3)
@@ -99,6 +99,9 @@ contains
     character(len=1), intent(in) :: bcs(:)
     integer, intent(in) :: ngrids_req          ! <= 0: the reference's rule
     type(slab_t), intent(in), optional :: slab ! this rank's z-slab of level 1 (distributed runs)
+    logical, intent(in), optional :: coarse_here  ! slab runs: do levels >= 2 live in this solver?  (default: on
+                                                  ! rank 0; .false. everywhere when level 2 is distributed too)
+    real(wp), intent(in), optional :: ext(2, 3)   ! see build_levels
     integer(c_int) :: rc
     integer :: l, d
     integer(c_size_t) :: nbytes
@@ -121,7 +124,7 @@ contains
     rc = ndsmk_init(-1_c_int)
     if (rc /= 0) return
 
-    call build_levels(ndim, nshape, qx, qy, qz, s%ngrids, s%lev)
+    call build_levels(ndim, nshape, qx, qy, qz, s%ngrids, s%lev, ext)
     do l = 1, s%ngrids
       call fill_grid_desc(ndim, s%lev(l), s%bcs)
     end do
@@ -134,6 +137,7 @@ contains
       s%slab = .true.
       s%sl = slab
       s%has_coarse = (slab%rank == 0)
+      if (present(coarse_here)) s%has_coarse = coarse_here
       call apply_slab_window(s%lev(1), s%sl)
       s%npts1 = s%plane1 * int(s%sl%nloc, ik)
     end if
@@ -565,24 +569,44 @@ contains
 
   ! z-slab level 1: restrict the slab's residual into its window of coarse planes
   ! [ck0, ck1) of cbuf (the planes are shipped to rank 0 by the caller)
-  function mg_slab_restrict(s) result(rc)
+  ! (dst, dst_k0 given: into that array of whole coarse planes instead, whose plane 0 is global
+  ! coarse plane dst_k0 - the rhs slab of the next level when that is distributed as well)
+  function mg_slab_restrict(s, dst, dst_k0) result(rc)
     type(mg_solver), intent(inout) :: s
+    type(c_ptr), intent(in), optional :: dst
+    integer, intent(in), optional :: dst_k0
     integer(c_int) :: rc
     type(ndsmk_xfer) :: x
     rc = 0
     if (s%sl%ck1 <= s%sl%ck0) return
     x = s%xf(1)%x
-    x%c_k0 = s%sl%cb0
-    x%c_beg = s%sl%ck0 - s%sl%cb0
     x%c_cnt = s%sl%ck1 - s%sl%ck0
-    rc = ndsmk_restrict(x, s%r, s%cbuf, c_null_ptr)
+    if (present(dst)) then
+      x%c_k0 = dst_k0
+      x%c_beg = s%sl%ck0 - dst_k0
+      rc = ndsmk_restrict(x, s%r, dst, c_null_ptr)
+    else
+      x%c_k0 = s%sl%cb0
+      x%c_beg = s%sl%ck0 - s%sl%cb0
+      rc = ndsmk_restrict(x, s%r, s%cbuf, c_null_ptr)
+    end if
   end function
 
-  ! z-slab level 1: u += P (coarse planes [pk0, pk1) received into cbuf)
-  function mg_slab_prolong(s) result(rc)
+  ! z-slab level 1: u += P (coarse planes [pk0, pk1) received into cbuf; or src, an array of whole
+  ! coarse planes starting at global coarse plane src_k0 that holds them)
+  function mg_slab_prolong(s, src, src_k0) result(rc)
     type(mg_solver), intent(inout) :: s
+    type(c_ptr), intent(in), optional :: src
+    integer, intent(in), optional :: src_k0
     integer(c_int) :: rc
-    rc = ndsmk_prolong_add(s%xf(1)%x, s%cbuf, s%dl(1)%u)
+    type(ndsmk_xfer) :: x
+    if (present(src)) then
+      x = s%xf(1)%x
+      x%c_k0 = src_k0
+      rc = ndsmk_prolong_add(x, src, s%dl(1)%u)
+    else
+      rc = ndsmk_prolong_add(s%xf(1)%x, s%cbuf, s%dl(1)%u)
+    end if
   end function
 
   ! ------------------------------------------------------------------

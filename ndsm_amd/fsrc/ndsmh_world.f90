@@ -37,7 +37,7 @@ module ndsmh_world
   private
 
   public :: mg_world, world_create, world_destroy, world_vcycle, world_solve, world_relax
-  public :: world_upload, world_download, world_plan_only
+  public :: world_upload, world_download, world_plan_only, world_set_params, world_dist_levels
 
   interface
     function ndsmk_dist_size() bind(c, name="ndsmk_dist_size") result(n)
@@ -88,16 +88,25 @@ module ndsmh_world
     type(slab_t), allocatable :: plan(:)     ! (0:nranks-1), identical on every rank
     integer :: ghost_depth = 0       ! this many ghost planes of u(1) per side match the neighbours' owned planes
     integer(ik) :: nzg = 0
+    ! The coarse problem.  Null: levels >= 2 live on rank 0 (restricted planes are gathered there,
+    ! corrections scattered back).  Associated: level 2 is distributed as well - a world of its
+    ! own over the same ranks, split where this level's restriction ownership puts the cuts, so
+    ! every rank restricts straight into its own coarse slab and prolongs from it: the plane
+    ! traffic to and from rank 0 moves one level down, where it is 8x smaller.
+    type(mg_world), pointer :: child => null()
+    integer :: level = 1             ! global level index of this world's slabs
   end type
 
 contains
 
   ! hierarchy + tables on the host only: the plan every rank derives (CPU tests)
-  function world_plan_only(nshape, qx, qy, qz, ngrids_req, nranks, plan) result(rc)
+  function world_plan_only(nshape, qx, qy, qz, ngrids_req, nranks, plan, part, min_depth, ext) result(rc)
     integer(c_int32_t), intent(in) :: nshape(3)
     real(wp), intent(in) :: qx(:), qy(:), qz(:)
     integer, intent(in) :: ngrids_req, nranks
     type(slab_t), allocatable, intent(out) :: plan(:)
+    integer, intent(in), optional :: part(0:), min_depth
+    real(wp), intent(in), optional :: ext(2, 3)
     integer(c_int) :: rc
     type(level_t), allocatable :: lev(:)
     type(axis_xfer_t) :: tz
@@ -107,27 +116,48 @@ contains
     ng = ndsm_level_count(3, nshape)
     if (ngrids_req > 0) ng = min(ng, ngrids_req)
     if (ng < 2) return
-    call build_levels(3, nshape, qx, qy, qz, ng, lev)
+    call build_levels(3, nshape, qx, qy, qz, ng, lev, ext)
     call build_axis_xfer(lev(1)%ax(3)%q, int(lev(1)%n(3)), lev(2)%ax(3)%q, int(lev(2)%n(3)), tz, ok)
     if (.not. ok) return
-    call plan_slabs(int(lev(1)%n(3)), int(lev(2)%n(3)), tz, nranks, plan, ok)
+    call plan_slabs(int(lev(1)%n(3)), int(lev(2)%n(3)), tz, nranks, plan, ok, part, min_depth)
     if (ok) rc = 0
   end function
 
-  ! rank < 0: loop-back world holding all nranks slabs in this process
-  function world_create(w, nshape, qx, qy, qz, bcs, ngrids_req, nranks, rank) result(rc)
+  ! rank < 0: loop-back world holding all nranks slabs in this process.
+  ! part / min_depth / level: set by the recursion when this world is the distributed coarse level
+  ! of another one.  How many levels get distributed: NDSM_HIP_DIST_LEVELS = k forces (up to) k
+  ! where the shapes allow it, unset/0 = while a rank's share of the next level is still a level
+  ! the fused kernels like (>= 2 M points and >= 16 planes per rank).
+  recursive function world_create(w, nshape, qx, qy, qz, bcs, ngrids_req, nranks, rank, part, min_depth, level, &
+                                  ext) result(rc)
     type(mg_world), intent(out) :: w
     integer(c_int32_t), intent(in) :: nshape(3)
     real(wp), intent(in) :: qx(:), qy(:), qz(:)
     character(len=1), intent(in) :: bcs(:)
     integer, intent(in) :: ngrids_req, nranks, rank
+    integer, intent(in), optional :: part(0:), min_depth, level
+    real(wp), intent(in), optional :: ext(2, 3)   ! origin / extent of the finest level of the whole hierarchy
     integer(c_int) :: rc
-    integer :: i
+    real(wp) :: ext1(2, 3)
+    integer :: i, r, ng, want, st, reach
+    integer, allocatable :: cpart(:)
+    type(slab_t), allocatable :: cplan(:)
+    integer(c_int32_t) :: n2(3)
+    logical :: dist
+    character(len=16) :: env
+    type(level_t), allocatable :: lev(:)
 
-    rc = world_plan_only(nshape, qx, qy, qz, ngrids_req, nranks, w%plan)
+    if (present(ext)) then
+      ext1 = ext
+    else
+      ext1(1, :) = [minval(qx), minval(qy), minval(qz)]
+      ext1(2, :) = [maxval(qx), maxval(qy), maxval(qz)] - ext1(1, :)
+    end if
+    rc = world_plan_only(nshape, qx, qy, qz, ngrids_req, nranks, w%plan, part, min_depth, ext1)
     if (rc /= 0) return
     w%nranks = nranks
     w%nzg = nshape(3)
+    if (present(level)) w%level = level
     if (rank < 0) then
       w%rccl = .false.; w%first = 0; w%nlocal = nranks
     else
@@ -136,18 +166,93 @@ contains
       if (nranks > 1 .and. (ndsmk_dist_size() /= nranks .or. ndsmk_dist_rank() /= rank)) return
       w%rccl = (nranks > 1); w%first = rank; w%nlocal = 1
     end if
+
+    ! ---- is the next level distributed too? -----------------------------
+    ng = ndsm_level_count(3, nshape)
+    if (ngrids_req > 0) ng = min(ng, ngrids_req)
+    dist = .false.
+    if (nranks > 1 .and. ng >= 3) then
+      call build_levels(3, nshape, qx, qy, qz, ng, lev, ext1)
+      n2 = lev(2)%n
+      want = 0
+      call get_environment_variable("NDSM_HIP_DIST_LEVELS", env, status=st)
+      if (st == 0) read (env, *, iostat=st) want
+      if (st /= 0) want = 0
+      if (want > 0) then
+        dist = w%level < want
+      else
+        dist = product(int(n2, ik)) / nranks >= 2_ik * 1024_ik * 1024_ik .and. &
+               minval(w%plan(:)%ck1 - w%plan(:)%ck0) >= 16
+      end if
+      ! the coarse slabs run on the fused smoother, and the coarse hierarchy must be the same
+      dist = dist .and. mod(n2(1), 2) == 0 .and. all(n2(1:2) >= 16) .and. ndsm_level_count(3, n2) >= ng - 1
+      if (dist) then
+        allocate (cpart(0:nranks))
+        cpart(0) = 0
+        reach = 0
+        do r = 0, nranks - 1
+          if (w%plan(r)%ck1 <= w%plan(r)%ck0 .or. w%plan(r)%ck0 /= cpart(r)) dist = .false.
+          cpart(r + 1) = w%plan(r)%ck1
+          reach = max(reach, w%plan(r)%ck0 - w%plan(r)%pk0, w%plan(r)%pk1 - w%plan(r)%ck1)
+        end do
+        if (cpart(nranks) /= n2(3)) dist = .false.
+      end if
+      if (dist) then      ! and the split must leave every rank a usable coarse slab
+        dist = world_plan_only(n2, lev(2)%ax(1)%q, lev(2)%ax(2)%q, lev(2)%ax(3)%q, ng - 1, nranks, cplan, &
+                               cpart, reach, ext1) == 0
+      end if
+    end if
+
     allocate (w%loc(w%nlocal))
     do i = 1, w%nlocal
-      rc = mg_create(w%loc(i), 3, nshape, qx, qy, qz, bcs, ngrids_req, w%plan(w%first + i - 1))
+      if (dist) then
+        rc = mg_create(w%loc(i), 3, nshape, qx, qy, qz, bcs, ngrids_req, w%plan(w%first + i - 1), &
+                       coarse_here=.false., ext=ext1)
+      else
+        rc = mg_create(w%loc(i), 3, nshape, qx, qy, qz, bcs, ngrids_req, w%plan(w%first + i - 1), ext=ext1)
+      end if
       if (rc /= 0) return
     end do
     w%ghost_depth = 0
+    if (dist) then
+      allocate (w%child)
+      rc = world_create(w%child, n2, lev(2)%ax(1)%q, lev(2)%ax(2)%q, lev(2)%ax(3)%q, bcs, ng - 1, nranks, rank, &
+                        cpart, reach, w%level + 1, ext1)
+      if (rc /= 0) return
+    end if
     rc = 0
   end function
 
-  subroutine world_destroy(w)
+  ! solver parameters of every slab solver, down the chain of distributed levels
+  recursive subroutine world_set_params(w, ms, ex_tol, use_max, nmax_exact)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: ms, nmax_exact
+    real(wp), intent(in) :: ex_tol
+    logical, intent(in) :: use_max
+    integer :: i
+    do i = 1, w%nlocal
+      w%loc(i)%ms = ms; w%loc(i)%ex_tol = ex_tol; w%loc(i)%use_max = use_max
+      w%loc(i)%nmax_exact = nmax_exact
+    end do
+    if (associated(w%child)) call world_set_params(w%child, ms, ex_tol, use_max, nmax_exact)
+  end subroutine
+
+  ! number of distributed levels (1 = only the finest)
+  recursive function world_dist_levels(w) result(n)
+    type(mg_world), intent(in) :: w
+    integer :: n
+    n = 1
+    if (associated(w%child)) n = 1 + world_dist_levels(w%child)
+  end function
+
+  recursive subroutine world_destroy(w)
     type(mg_world), intent(inout) :: w
     integer :: i
+    if (associated(w%child)) then
+      call world_destroy(w%child)
+      deallocate (w%child)
+      w%child => null()
+    end if
     if (allocated(w%loc)) then
       do i = 1, size(w%loc)
         call mg_destroy(w%loc(i))
@@ -396,7 +501,7 @@ contains
     end do
   end function
 
-  function world_vcycle(w) result(rc)
+  recursive function world_vcycle(w) result(rc)
     type(mg_world), intent(inout) :: w
     integer(c_int) :: rc
     integer :: i
@@ -412,27 +517,51 @@ contains
       end do
     end if
     rc = exchange(w, MG_BUF_R, w%plan(0)%g); if (rc /= 0) return
-    do i = 1, w%nlocal
-      rc = mg_slab_restrict(w%loc(i)); if (rc /= 0) return
-    end do
-    rc = gather_coarse(w); if (rc /= 0) return
+    if (associated(w%child)) then
+      ! ---- the next level is distributed as well: every rank restricts its coarse planes straight
+      ! into its own slab of the child's right-hand side, the child runs its part of the cycle
+      ! (V-cycle from its level + the sweeps that precede an interpolation, :642-644), and the
+      ! correction is interpolated from the child's own slab (its ghosts made current first)
+      associate (c => w%child)
+        do i = 1, w%nlocal
+          rc = mg_slab_restrict(w%loc(i), c%loc(i)%dl(1)%rhs, c%loc(i)%sl%k0); if (rc /= 0) return
+          rc = ndsmk_fill0(c%loc(i)%dl(1)%u, int(c%loc(i)%npts1, c_size_t) * R8)   ! :557-558
+          if (rc /= 0) return
+          call mg_mark_rhs_set(c%loc(i))
+          c%loc(i)%ms = w%loc(i)%ms
+        end do
+        rc = exchange(c, MG_BUF_RHS, c%plan(0)%g); if (rc /= 0) return   ! redundant ghost updates read rhs there
+        c%ghost_depth = c%plan(0)%g                                        ! u = 0 everywhere: ghosts are current
+        rc = world_vcycle(c); if (rc /= 0) return
+        rc = world_relax(c, c%loc(1)%ms); if (rc /= 0) return
+        rc = need_ghosts(c, c%plan(0)%g); if (rc /= 0) return
+        do i = 1, w%nlocal
+          rc = mg_slab_prolong(w%loc(i), c%loc(i)%dl(1)%u, c%loc(i)%sl%k0); if (rc /= 0) return
+        end do
+      end associate
+    else
+      do i = 1, w%nlocal
+        rc = mg_slab_restrict(w%loc(i)); if (rc /= 0) return
+      end do
+      rc = gather_coarse(w); if (rc /= 0) return
 
-    ! ---- levels >= 2 on rank 0 ------------------------------------------
-    do i = 1, w%nlocal
-      if (w%loc(i)%sl%rank /= 0) cycle
-      if (w%loc(i)%ngrids == 2) then
-        rc = mg_op(w%loc(i), MG_OP_EXACT, 2, 1); if (rc /= 0) return
-      else
-        rc = mg_vcycle_from(w%loc(i), 2); if (rc /= 0) return
-      end if
-      rc = mg_op(w%loc(i), MG_OP_RELAX, 2, w%loc(i)%ms); if (rc /= 0) return   ! :642-644
-    end do
+      ! ---- levels >= 2 on rank 0 ------------------------------------------
+      do i = 1, w%nlocal
+        if (w%loc(i)%sl%rank /= 0) cycle
+        if (w%loc(i)%ngrids == 2) then
+          rc = mg_op(w%loc(i), MG_OP_EXACT, 2, 1); if (rc /= 0) return
+        else
+          rc = mg_vcycle_from(w%loc(i), 2); if (rc /= 0) return
+        end if
+        rc = mg_op(w%loc(i), MG_OP_RELAX, 2, w%loc(i)%ms); if (rc /= 0) return   ! :642-644
+      end do
 
-    ! ---- level 1, upwards (coarse_to_fine, :593-684) --------------------
-    rc = scatter_coarse(w); if (rc /= 0) return
-    do i = 1, w%nlocal
-      rc = mg_slab_prolong(w%loc(i)); if (rc /= 0) return
-    end do
+      ! ---- level 1, upwards (coarse_to_fine, :593-684) --------------------
+      rc = scatter_coarse(w); if (rc /= 0) return
+      do i = 1, w%nlocal
+        rc = mg_slab_prolong(w%loc(i)); if (rc /= 0) return
+      end do
+    end if
     w%ghost_depth = 0
     rc = world_relax(w, w%loc(1)%ms)
   end function

@@ -542,3 +542,37 @@ def test_slab_world_laplace_variant(hip):
     assert np.array_equal(W.download(hip.BUF_U), S.download(1, hip.BUF_U))
     S.close()
     W.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns,nranks,levels", (([64, 64, 256], 4, 2), ([128, 64, 256], 2, 3), ([64, 64, 384], 8, 2)), ids=str)
+def test_slab_world_distributed_coarse_levels(hip, ns, nranks, levels):
+    """several distributed levels (NDSM_HIP_DIST_LEVELS; by default chosen by size): every rank
+    restricts straight into its own slab of the next level's rhs and prolongs from it, only the first
+    non-distributed level travels to rank 0.  Loop-back world vs the single-domain solver: V-cycles and
+    a whole solve, bit for bit."""
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
+    os.environ["NDSM_HIP_DIST_LEVELS"] = str(levels)
+    try:
+        for bcs in ("NDDNDD", "DDNDDN"):
+            S = hip.MGSolver(ns, mesh, bcs)
+            W = hip.World(ns, mesh, bcs, nranks)
+            assert W.dist_levels == levels, W.dist_levels
+            for X in (S,):
+                X.upload(1, hip.BUF_U, u)
+                X.upload(1, hip.BUF_RHS, rhs)
+            W.upload(hip.BUF_U, u)
+            W.upload(hip.BUF_RHS, rhs)
+            S.vcycle(2)
+            W.vcycle(2)
+            assert np.array_equal(W.download(hip.BUF_U), S.download(1, hip.BUF_U)), f"vcycle {bcs}"
+            ie1, du1, nc1, h1 = S.solve(hist_len=64)
+            ie2, du2, nc2, h2 = W.solve(hist_len=64)
+            assert (ie1, nc1) == (ie2, nc2) and np.array_equal(h1, h2), (bcs, nc1, nc2)
+            assert np.array_equal(W.download(hip.BUF_U), S.download(1, hip.BUF_U)), f"solve {bcs}"
+            S.close()
+            W.close()
+    finally:
+        os.environ.pop("NDSM_HIP_DIST_LEVELS", None)
