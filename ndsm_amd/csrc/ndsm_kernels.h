@@ -142,7 +142,8 @@ int ndsmk_balance_curl(double *A, double *B, const int32_t *n3, const double *x,
  * result (may be NULL).  prev: have the launch of the last sweep evaluate max / sum |u_new - prev|
  * (*met_done = 1 if it did; ndsmk_fetch_fused_metric reads the pair, blocking). */
 int ndsmk_relax3(const ndsmk_grid *g, double *u, double *a, double *b, const double *keep, const double *rhs,
-                 int nsweeps, double *r, const double *prev, int *where, int *met_done);
+                 int nsweeps, double *r, const double *prev, int *where, int *met_done,
+                 const ndsmk_xfer *px /* != NULL: u += P uc first */, const double *uc);
 int ndsmk_fetch_fused_metric(double *h_out2);
 
 /* ---- mixed-precision mode (mixed.hip): level 1 as iterative refinement, correction in fp32 ---- */

@@ -15,7 +15,8 @@
 
 namespace ndsm {
 int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
-                       bool force, int *sweeps_done, double *rout, int *res_done, const double *prev, int *met_done);
+                       bool force, int *sweeps_done, double *rout, int *res_done, const double *prev, int *met_done,
+                       const ndsmk_xfer *px, const double *uc);
 int fetch_fused_metric(double *h_out2);
 int launch_mean_shift(double *u, int64_t n);
 }
@@ -120,8 +121,11 @@ __global__ __launch_bounds__(256) void rbgs2_color(double *__restrict__ u, const
 // ping-pong); *where tells which buffer holds the result.  keep: a buffer that must survive (the
 // iterate the V-cycle started from, which the convergence metric is taken against); prev: evaluate
 // that metric in the launch of the last sweep (*met_done).  rout: residual on the last sweep.
+// px / uc: u += P uc comes first (coarse_to_fine); folded into the loads of the first launch
+// where that launch is the two-sweep Laplace one, else done by the stand-alone kernel.
 static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double *keep, const double *rhs, int nsweeps,
-                      int variant, int *where, double *rout, int *res_done, const double *prev, int *met_done) {
+                      int variant, int *where, double *rout, int *res_done, const double *prev, int *met_done,
+                      const ndsmk_xfer *px = nullptr, const double *uc = nullptr) {
   NDSM_REQUIRE_READY();
   if (res_done) *res_done = 0;
   if (met_done) *met_done = 0;
@@ -136,6 +140,11 @@ static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double 
   const int mx = g.ub[0] - g.lb[0] + 1, my = g.ub[1] - g.lb[1] + 1, mz = g.ub[2] - g.lb[2] + 1;
   int cur = 0;
   if (where) *where = 0;
+  bool prol_pending = px != nullptr;
+  if (prol_pending && (nsweeps <= 0 || mx <= 0 || my <= 0 || (g.ndim == 3 && mz <= 0))) {
+    if (int rc = ndsmk_prolong_add(px, uc, bufs[0])) return rc;
+    prol_pending = false;
+  }
   if (mx <= 0 || my <= 0 || (g.ndim == 3 && mz <= 0)) return 0;  // nothing to update
   // an in-place kernel may not touch the buffer the caller wants kept
   auto in_place_ok = [&]() { return keep == nullptr || bufs[cur] != keep; };
@@ -143,6 +152,9 @@ static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double 
   if (g.ndim == 3 && variant == 0 && !g.all_neumann && npts <= 4096 && g.k0 == 0 && g.zown0 == 0 &&
       g.zown1 == g.n[2] && nsweeps > 0) {
     NDSM_CHECK_ARG(in_place_ok());
+    if (prol_pending) {
+      if (int rc = ndsmk_prolong_add(px, uc, bufs[0])) return rc;
+    }
     hipLaunchKernelGGL(rbgs3_small, dim3(1), dim3(1024), 0, s, bufs[0], rhs, g, nsweeps);
     NDSM_LAUNCH_CHECK();
     return 0;
@@ -161,10 +173,23 @@ static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double 
           }
         // all-Neumann levels shift the mean after EVERY sweep: one sweep per pass there
         int ndone = 0;
+        if (prol_pending) {  // first pass: try the launch that interpolates while it loads
+          int rc = ndsm::launch_rbgs3_fused(g, u, dst >= 0 ? bufs[dst] : nullptr, rhs, g.all_neumann ? 1 : nsweeps - sw,
+                                            variant == 2, &ndone, nullptr, nullptr, nullptr, nullptr, px, uc);
+          if (rc) return rc;
+          if (ndone == 0) {  // not that launch: interpolate in place, then sweep as usual
+            NDSM_CHECK_ARG(in_place_ok());
+            rc = ndsmk_prolong_add(px, uc, u);
+            if (rc) return rc;
+          }
+          prol_pending = false;
+        }
         // the residual rides on the last sweep (not on all-Neumann levels: the mean shift comes in between)
-        int rc = ndsm::launch_rbgs3_fused(g, u, dst >= 0 ? bufs[dst] : nullptr, rhs, g.all_neumann ? 1 : nsweeps - sw,
-                                          variant == 2, &ndone, g.all_neumann ? nullptr : rout, res_done,
-                                          g.all_neumann ? nullptr : prev, met_done);
+        int rc = ndone > 0 ? 0
+                           : ndsm::launch_rbgs3_fused(g, u, dst >= 0 ? bufs[dst] : nullptr, rhs,
+                                                      g.all_neumann ? 1 : nsweeps - sw, variant == 2, &ndone,
+                                                      g.all_neumann ? nullptr : rout, res_done,
+                                                      g.all_neumann ? nullptr : prev, met_done, nullptr, nullptr);
         if (rc) return rc;
         done = ndone > 0;
         if (done) {  // the sweeps landed in the other array
@@ -174,6 +199,11 @@ static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double 
         }
         if (!done && variant == 2)
           return ndsm::fail(NDSMK_EARG, "fused smoother does not support this level shape", __FILE__, __LINE__);
+      }
+      if (!done && prol_pending) {
+        NDSM_CHECK_ARG(in_place_ok());
+        if (int rc = ndsmk_prolong_add(px, uc, u)) return rc;
+        prol_pending = false;
       }
       if (!done) {
         if (g.zown0 != 0 || g.zown1 != g.n[2])
@@ -190,6 +220,10 @@ static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double 
       }
     } else {
       NDSM_CHECK_ARG(in_place_ok());
+      if (prol_pending) {
+        if (int rc = ndsmk_prolong_add(px, uc, u)) return rc;
+        prol_pending = false;
+      }
       const int half = (mx + 1) / 2;
       dim3 block(64, 4, 1);
       dim3 grid((half + 63) / 64, (my + 3) / 4, 1);
@@ -242,13 +276,14 @@ extern "C" int ndsmk_relax_residual(const ndsmk_grid *gp, double *u, double *ual
 // which buffer holds the result.  r != NULL: residual of the result (fused into the last sweep's
 // launch where possible).  prev != NULL: the launch of the last sweep also evaluates
 // max / sum |u_new - prev| (*met_done = 1; read it with ndsmk_fetch_fused_metric), if it can.
+// px != NULL: u += P uc (the coarse-grid correction) comes before the sweeps.
 extern "C" int ndsmk_relax3(const ndsmk_grid *gp, double *u, double *a, double *b, const double *keep,
                             const double *rhs, int nsweeps, double *r, const double *prev, int *where,
-                            int *met_done) {
+                            int *met_done, const ndsmk_xfer *px, const double *uc) {
   NDSM_CHECK_ARG(where != nullptr && met_done != nullptr && u && a);
   int res_done = 0;
   double *const bufs[3] = {u, a, b};
-  int rc = relax_impl(gp, bufs, keep, rhs, nsweeps, 0, where, r, &res_done, prev, met_done);
+  int rc = relax_impl(gp, bufs, keep, rhs, nsweeps, 0, where, r, &res_done, prev, met_done, px, uc);
   if (rc) return rc;
   if (r && !res_done) rc = ndsmk_residual(gp, bufs[*where], rhs, r);
   return rc;

@@ -34,6 +34,14 @@
 
 namespace {
 
+// MODE 3: tables of the interpolation from the next coarser level (ndsmk_xfer's prolongation half)
+struct ProlArgs {
+  const double *uc;          // coarse u (whole level)
+  const int32_t *plo[3];     // per fine index: lower bracket in the coarse axis
+  const double *pwl[3], *pwh[3];
+  int ncx, ncy, ncz;
+};
+
 struct FusedPlan {
   int ntx, nty, nzc;  // tiles in x, y and chunks in z
   int zc;             // planes per chunk
@@ -133,13 +141,21 @@ struct Slot {
 // it stores, against the iterate the cycle started from (prev; the V-cycle driver keeps that
 // buffer untouched) - per-workgroup partials, folded by fold_metric_k.  Replaces a separate
 // 24 B/pt pass (read u, read prev, write prev) by one more 8 B/pt read here.
+//
+// MODE 3 (PROL): the launch that starts the post-smoothing adds the coarse-grid correction to
+// every plane as it is loaded - u + P u_c never makes a round trip through HBM of its own
+// (coarse_to_fine's interpolate + add_correction, ndsm_multigrid_core.f90:593-684; same
+// expressions and order as prolong_add_k: z first, then y, then x).  Per fine plane the
+// workgroup forms the z-interpolated coarse plane of its tile ONCE (one or two coarse points per
+// thread, their values of the two bracketing coarse planes rolling through registers) and
+// parks it in LDS; each fine point then needs four LDS reads and nine flops.
 template <typename T, int S, int TXH, int TYH, int NT, int WPS, bool RHS0, int MODE>
 __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u, T *__restrict__ uout,
                                                          const T *__restrict__ rhs, T *__restrict__ rout,
                                                          const T *__restrict__ prev, double *__restrict__ part,
-                                                         ndsmk_grid g, FusedPlan pl) {
+                                                         ndsmk_grid g, FusedPlan pl, ProlArgs pa) {
   using d2 = P2<T>;
-  constexpr bool RES = MODE == 1, MET = MODE == 2;
+  constexpr bool RES = MODE == 1, MET = MODE == 2, PROL = MODE == 3;
   constexpr int SZ = (int)sizeof(T);
   constexpr bool DEFER = !RES;
   const T gw0 = (T)g.w[0], gw1 = (T)g.w[1], gw2 = (T)g.w[2], gw1i = (T)g.w1, gwc = (T)g.wc;
@@ -280,6 +296,113 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   char *const ldsb = reinterpret_cast<char *>(lds);
 #define LDSD(off) (*reinterpret_cast<T *>(ldsb + (off)))
 
+  // ---- PROL: coarse footprint of the tile, per-thread interpolation constants ----
+  constexpr int CW = TXH / 2 + 3, CH = TYH / 2 + 3;  // coarse points the tile can touch (ratio >= ~1.97)
+  constexpr int NCS = PROL ? (CW * CH + NT - 1) / NT : 1;
+  // z-interpolated coarse planes, double buffered: the plane of fine plane kf sits in tile kf & 1,
+  // parked one iteration before it is needed so that the correction runs before the barrier
+  double *const czt0 = reinterpret_cast<double *>(ldsb + NSTG * PLANE * SZ);
+  int cx0 = 0, cy0 = 0, kcur = 0;
+  int p_il[PROL ? NS : 1][2], p_jl[PROL ? NS : 1];
+  double p_wlx[PROL ? NS : 1][2], p_whx[PROL ? NS : 1][2], p_wly[PROL ? NS : 1], p_why[PROL ? NS : 1];
+  double c_lo[NCS], c_hi[NCS], c_nx[NCS];
+  size_t c_off[NCS];
+  bool c_ok[NCS];
+  if (PROL) {
+    const int ia = max(x0, 0), ja = max(y0, 0);
+    cx0 = pa.plo[0][ia];
+    cy0 = pa.plo[1][ja];
+#pragma unroll
+    for (int s = 0; s < (PROL ? NS : 1); ++s) {
+      const SlotT q(tid, s, x0, y0, nx, ny);
+      p_jl[s] = 0;
+      p_wly[s] = p_why[s] = 0.0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        p_il[s][h] = 0;
+        p_wlx[s][h] = p_whx[s][h] = 0.0;
+      }
+      if (q.in) {
+        p_jl[s] = pa.plo[1][q.j] - cy0;
+        p_wly[s] = pa.pwl[1][q.j];
+        p_why[s] = pa.pwh[1][q.j];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          p_il[s][h] = pa.plo[0][q.i + h] - cx0;
+          p_wlx[s][h] = pa.pwl[0][q.i + h];
+          p_whx[s][h] = pa.pwh[0][q.i + h];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) {
+      const int idx = tid + NT * c;
+      const int a = idx % CW, b = idx / CW;
+      c_ok[c] = b < CH && cx0 + a < pa.ncx && cy0 + b < pa.ncy;
+      c_off[c] = c_ok[c] ? (size_t)(cx0 + a) + (size_t)pa.ncx * (size_t)(cy0 + b) : 0;
+      c_lo[c] = c_hi[c] = c_nx[c] = 0.0;
+    }
+  }
+  const size_t csz = PROL ? (size_t)pa.ncx * (size_t)pa.ncy : 0;
+  // coarse planes kcur, kcur+1 (and, prefetched, kcur+2) of this thread's coarse points
+  auto prol_load = [&](int kc, double *dst) {
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) dst[c] = (c_ok[c] && kc < pa.ncz) ? pa.uc[csz * (size_t)kc + c_off[c]] : 0.0;
+  };
+  // advance the rolling coarse planes to the bracket of fine plane kf and park its z-interpolated
+  // coarse plane in LDS (the caller puts a barrier between this and prol_corr)
+  // (the z tables are read one plane ahead: a scalar load issued and consumed in the same
+  // iteration costs its whole latency on every plane)
+  int zt_kc = 0;
+  double zt_wl = 0.0, zt_wh = 0.0;
+  auto prol_ztab = [&](int kf) {
+    const int kq = min(max(kf, 0), nz - 1);
+    zt_kc = pa.plo[2][kq];
+    zt_wl = pa.pwl[2][kq];
+    zt_wh = pa.pwh[2][kq];
+  };
+  auto prol_stage = [&](int kf) {
+    double *const czt = czt0 + (kf & 1) * (CW * CH);
+    const int kc = zt_kc;
+    const double wlz = zt_wl, whz = zt_wh;
+    prol_ztab(kf + 1);
+    if (kc > kcur) {  // the bracket moves up by at most one coarse plane per fine plane
+#pragma unroll
+      for (int c = 0; c < NCS; ++c) {
+        c_lo[c] = c_hi[c];
+        c_hi[c] = c_nx[c];
+      }
+      kcur = kc;
+      prol_load(kcur + 2, c_nx);
+    }
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) {
+      const int idx = tid + NT * c;
+      if (idx < CW * CH) czt[idx] = whz * c_lo[c] + wlz * c_hi[c];  // last dimension first (ndsm_interp.f90:128-154)
+    }
+  };
+  // u + P u_c for this thread's pairs of the fine plane whose coarse plane is parked
+  auto prol_corr = [&](d2 *pl_, int kf) {
+    const double *const czt = czt0 + (kf & 1) * (CW * CH);
+#pragma unroll
+    for (int s = 0; s < (PROL ? NS : 1); ++s) {
+      if (!(scs[s].fl & 1)) continue;
+      const double *r0 = czt + p_jl[s] * CW, *r1 = r0 + CW;
+      double v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int il = p_il[s][h];
+        double f0 = r0[il], f1 = r0[il + 1];
+        const double f2 = r1[il], f3 = r1[il + 1];
+        f0 = p_why[s] * f0 + p_wly[s] * f2;
+        f1 = p_why[s] * f1 + p_wly[s] * f3;
+        v[h] = p_whx[s][h] * f0 + p_wlx[s][h] * f1;
+      }
+      pl_[s].x = (T)((double)pl_[s].x + v[0]);
+      pl_[s].y = (T)((double)pl_[s].y + v[1]);
+    }
+  };
+
   // ---- prologue: plane ks into its LDS buffer, plane ks+1 into registers ----
   {
     d2 c0[NS];
@@ -291,6 +414,20 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rw[s][0] = r0[s];
     }
     if (ks + 1 <= ke) NDSM_LOAD_PLANE(u, ks + 1, nxt);
+    if (PROL) {  // the two planes loaded here get their correction here
+      kcur = pa.plo[2][ks];
+      prol_ztab(ks);
+      prol_load(kcur, c_lo);
+      prol_load(kcur + 1, c_hi);
+      prol_load(kcur + 2, c_nx);
+      prol_stage(ks);
+      if (ks + 1 <= ke) prol_stage(ks + 1);
+      __syncthreads();
+      prol_corr(c0, ks);
+      if (ks + 1 <= ke) prol_corr(nxt, ks + 1);
+      __syncthreads();
+      if (ks + 2 <= ke) prol_stage(ks + 2);  // for the first iteration; published by the barrier below
+    }
     T *B0 = lds + (ks % NSTG) * PLANE;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -319,6 +456,11 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       }
       return b * (PLANE * SZ);
     };
+    // PROL: park the z-interpolated coarse plane of fine plane k+3 (the other tile: plane k+2's
+    // was parked an iteration ago and is read further down, before the barrier).  BEFORE this
+    // iteration's loads are issued: it consumes a prefetched coarse plane, and a vmcnt wait placed
+    // after the new loads would wait for those too.
+    if (PROL && k + 3 <= ke) prol_stage(k + 3);
     // request plane k+2 of u and plane k+1 of rhs before touching plane k
     if (k + 2 <= ke) {
       const T *pk = u + sz * (size_t)(k + 2);
@@ -332,6 +474,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       for (int s = 0; s < (RHS0 ? 1 : NS); ++s)
         if (scs[s].fl & 1) rn[s] = ld2(pk + scs[s].go);
     }
+
 
     // MET: the previous iterate of the plane this iteration will store
     d2 pvh[MET ? NS : 1];
@@ -396,6 +539,10 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
         zplus[s] = upd ? nw : cur[s];  // z+1 neighbour of the next stage's plane
       }
     }
+
+    // PROL: the correction of the plane that arrived during the stages (its coarse plane was parked
+    // one iteration ago), done here so that it overlaps with other waves' stages
+    if (PROL && k + 2 <= ke) prol_corr(nn, k + 2);
 
     // Results of this iteration that go to HBM.  DEFER: they are STORED only after the window shift
     // below has consumed the loads of plane k+2: vmcnt counts stores as well, and a store issued
@@ -572,7 +719,7 @@ int met_scratch(size_t nblk, double **part, double **out2) {
 
 template <typename T, int S, int TXH, int TYH, int NT, int WPS, int MODE = 0>
 int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int target_wgs, T *rout = nullptr,
-               const T *prev = nullptr) {
+               const T *prev = nullptr, const ProlArgs *prol = nullptr) {
   constexpr bool RES = MODE == 1;
   constexpr int NST = RES ? 2 * S + 1 : 2 * S;
   constexpr int TXI = TXH - 2 * ((NST + 1) & ~1), TYI = TYH - 2 * NST;
@@ -582,7 +729,7 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
   pl.nty = (g.n[1] + TYI - 1) / TYI;
   const int tiles = pl.ntx * pl.nty;
   const int nzo = g.zown1 - g.zown0;  // owned planes
-  const size_t lds_bytes = sizeof(T) * NST * TXH * TYH;
+  const size_t lds_bytes = sizeof(T) * NST * TXH * TYH + (MODE == 3 ? 2 * sizeof(double) * (TXH / 2 + 3) * (TYH / 2 + 3) : 0);
   static bool attr_set[2] = {false, false};
   static int wgs_per_cu[2] = {1, 1};
   const int v = rhs ? 0 : 1;
@@ -629,18 +776,20 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
   pl.nzc = (nzo + pl.zc - 1) / pl.zc;
   pl.nwork = tiles * pl.nzc;
   const int nblk = ((pl.nwork + 7) / 8) * 8;
+  ProlArgs pa = {};
+  if (prol) pa = *prol;
   double *part = nullptr, *out2 = nullptr;
   if (MODE == 2) {
     if (int rc = met_scratch((size_t)nblk, &part, &out2)) return rc;
   }
   if (rhs)
     hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE>), dim3(nblk), dim3(NT), lds_bytes,
-                       ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl);
+                       ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl, pa);
   else  // the level's rhs is identically zero (level 1 of NDSM's Laplace problems,
         // ndsm_vector_potential.f90:640-641): x - 0.0 == x exactly, so the variant that never
         // loads rhs returns the same bits with 8 B/LUP less traffic
     hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE>), dim3(nblk), dim3(NT), lds_bytes,
-                       ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl);
+                       ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl, pa);
   NDSM_LAUNCH_CHECK();
   if (MODE == 2) {
     hipLaunchKernelGGL(fold_metric_k, dim3(1), dim3(256), 0, ndsm::stream(), part, nblk, out2);
@@ -674,7 +823,8 @@ static const int *fused_cfg() {
 // max_sweeps sweeps, i.e. when this call runs a single sweep with max_sweeps == 1.
 template <typename T>
 static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int max_sweeps, bool force,
-                          int *sweeps_done, T *rout, int *res_done, const T *prev = nullptr, int *met_done = nullptr) {
+                          int *sweeps_done, T *rout, int *res_done, const T *prev = nullptr, int *met_done = nullptr,
+                          const ProlArgs *prol = nullptr) {
   *sweeps_done = 0;
   if (res_done) *res_done = 0;
   if (met_done) *met_done = 0;
@@ -700,6 +850,19 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   // prev != nullptr: the launch that performs the last of the max_sweeps sweeps also evaluates
   // the convergence metric against prev (fp64, single domain; *met_done says it did)
   const bool met = std::is_same<T, double>::value && prev && met_done && !slab;
+  // prol != nullptr: u + P u_c is to be formed while the planes are loaded (MODE 3).  Built for
+  // the two-sweep Laplace launch only; if this call cannot be that launch NOTHING is launched
+  // (*sweeps_done = 0) and the caller interpolates with the stand-alone kernel first.
+  if (prol) {
+    if constexpr (std::is_same<T, double>::value) {
+      if (!rhs && two && !slab && !(met && max_sweeps == 2) && cfg[0] == 0) {
+        rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 3>(g, u, uout, rhs, tgt, nullptr, nullptr, prol));
+        if (rc) return rc;
+        *sweeps_done = 2;
+      }
+    }
+    return 0;
+  }
   if constexpr (std::is_same<T, double>::value) {
     if (met && two && max_sweeps == 2) {
       rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 2>(g, u, uout, rhs, tgt, nullptr, prev));
@@ -750,7 +913,24 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
 
 int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
                        bool force, int *sweeps_done, double *rout, int *res_done, const double *prev,
-                       int *met_done) {
+                       int *met_done, const ndsmk_xfer *px, const double *uc) {
+  if (px) {
+    ProlArgs pa;
+    pa.uc = uc;
+    for (int d = 0; d < 3; ++d) {
+      pa.plo[d] = px->plo[d];
+      pa.pwl[d] = px->pwl[d];
+      pa.pwh[d] = px->pwh[d];
+    }
+    pa.ncx = px->nc[0];
+    pa.ncy = px->nc[1];
+    pa.ncz = px->nc[2];
+    if (px->f_k0 != 0 || px->c_k0 != 0 || px->nf[0] != g.n[0] || px->nf[1] != g.n[1] || px->nf[2] != g.n[2]) {
+      *sweeps_done = 0;  // windows (z-slabs) are not built into this mode
+      return 0;
+    }
+    return launch_fused_t<double>(g, u, uout, rhs, max_sweeps, force, sweeps_done, rout, res_done, prev, met_done, &pa);
+  }
   return launch_fused_t<double>(g, u, uout, rhs, max_sweeps, force, sweeps_done, rout, res_done, prev, met_done);
 }
 

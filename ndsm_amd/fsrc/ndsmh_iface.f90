@@ -135,11 +135,12 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
-    function ndsmk_relax3(g, u, a, b, keep, rhs, nsweeps, r, prev, where, met_done) &
+    ! px: c_loc of an ndsmk_xfer (u += P uc before the sweeps) or c_null_ptr
+    function ndsmk_relax3(g, u, a, b, keep, rhs, nsweeps, r, prev, where, met_done, px, uc) &
         bind(c, name="ndsmk_relax3") result(rc)
       import :: ndsmk_grid, c_ptr, c_int
       type(ndsmk_grid), intent(in) :: g
-      type(c_ptr), value :: u, a, b, keep, rhs, r, prev
+      type(c_ptr), value :: u, a, b, keep, rhs, r, prev, px, uc
       integer(c_int), value :: nsweeps
       integer(c_int), intent(out) :: where, met_done
       integer(c_int) :: rc

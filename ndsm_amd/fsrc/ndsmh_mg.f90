@@ -505,17 +505,26 @@ contains
   end function
 
   ! level-1 sweeps in track mode: three rotating buffers, s%keep is never written
-  function relax_tracked(s, nsweeps, with_res, last) result(rc)
-    type(mg_solver), intent(inout) :: s
+  ! (prolong: u(1) += P u(2) first - folded into the first launch's loads where possible)
+  function relax_tracked(s, nsweeps, with_res, last, prolong) result(rc)
+    type(mg_solver), intent(inout), target :: s
     integer, intent(in) :: nsweeps
     logical, intent(in) :: with_res, last
+    logical, intent(in), optional :: prolong
     integer(c_int) :: rc
     integer(c_int) :: where, met
-    type(c_ptr) :: b(0:2), rr, pv
+    type(c_ptr) :: b(0:2), rr, pv, px, uc
     b(0) = s%dl(1)%u; b(1) = s%dl(1)%ualt; b(2) = s%prev
     rr = c_null_ptr; if (with_res) rr = s%r
     pv = c_null_ptr; if (last) pv = s%keep
-    rc = ndsmk_relax3(s%lev(1)%g, b(0), b(1), b(2), s%keep, rhs_of(s, 1), int(nsweeps, c_int), rr, pv, where, met)
+    px = c_null_ptr; uc = c_null_ptr
+    if (present(prolong)) then
+      if (prolong) then
+        px = c_loc(s%xf(1)%x); uc = s%dl(2)%u
+      end if
+    end if
+    rc = ndsmk_relax3(s%lev(1)%g, b(0), b(1), b(2), s%keep, rhs_of(s, 1), int(nsweeps, c_int), rr, pv, where, met, &
+                      px, uc)
     if (rc /= 0) return
     if (last) s%met_done = (met /= 0)
     s%dl(1)%u = b(where)
@@ -561,8 +570,12 @@ contains
     ! (coarse_to_fine, :593-684)
     do l = s%ngrids, ltop + 1, -1
       rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
-      rc = mg_op(s, MG_OP_PROLONG, l - 1, 1); if (rc /= 0) return
-      rc = mg_op(s, merge(MG_OP_RELAX_LAST, MG_OP_RELAX, l - 1 == 1), l - 1, s%ms); if (rc /= 0) return
+      if (l - 1 == 1 .and. s%track) then      ! interpolate + correct + post-smooth as one call
+        rc = relax_tracked(s, s%ms, .false., .true., prolong=.true.); if (rc /= 0) return
+      else
+        rc = mg_op(s, MG_OP_PROLONG, l - 1, 1); if (rc /= 0) return
+        rc = mg_op(s, merge(MG_OP_RELAX_LAST, MG_OP_RELAX, l - 1 == 1), l - 1, s%ms); if (rc /= 0) return
+      end if
     end do
     rc = 0
   end function
