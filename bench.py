@@ -142,7 +142,7 @@ def main():
     rccl_ok, rccl_err, slab_mode = True, "", False
     if world > 1:
         import faulthandler
-        faulthandler.dump_traceback_later(900, exit=True)   # a wedged collective must not hang the node
+        faulthandler.dump_traceback_later(600, exit=True)   # a wedged collective must not hang the node
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
