@@ -576,3 +576,62 @@ def test_slab_world_distributed_coarse_levels(hip, ns, nranks, levels):
             W.close()
     finally:
         os.environ.pop("NDSM_HIP_DIST_LEVELS", None)
+
+
+@pytest.mark.gpu
+def test_interpolation_reproduces_trilinear_functions(hip):
+    """the reference's unit_test_interp property (tests/unit_tests/unit_test_interp.f90:42-181): the
+    interpolation is exact (to rounding) for functions that are linear in every coordinate - here
+    through both prolongation kernels (tiled for the large level pair, gather for a small one) on the
+    non-nested meshes, including the last fine points that lie on the coarse mesh's end."""
+    for ns in ([200, 100, 70], [64, 40, 24]):
+        mesh = uniform_mesh(ns)
+        S = hip.MGSolver(ns, mesh, "DDDDDD")
+        nc = S.shapes[1]
+        rng = np.random.default_rng(7)
+        c = rng.uniform(-1, 1, 8)
+        f = lambda X, Y, Z: (c[0] + c[1] * X + c[2] * Y + c[3] * Z + c[4] * X * Y + c[5] * Y * Z + c[6] * X * Z  # noqa: E731
+                             + c[7] * X * Y * Z)
+        cm = [np.linspace(m[0], m[-1], n) for m, n in zip(mesh, nc)]
+        Zc, Yc, Xc = np.meshgrid(cm[2], cm[1], cm[0], indexing="ij")
+        Zf, Yf, Xf = np.meshgrid(mesh[2], mesh[1], mesh[0], indexing="ij")
+        S.upload(2, hip.BUF_U, f(Xc, Yc, Zc))
+        S.upload(1, hip.BUF_U, np.zeros(tuple(ns[::-1])))
+        S.op(hip.OP_PROLONG, 1)
+        got = S.download(1, hip.BUF_U)
+        want = f(Xf, Yf, Zf)
+        assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), np.abs(got - want).max()
+        S.close()
+
+
+@pytest.mark.gpu
+def test_full_size_config3_properties(hip):
+    """BASELINE config[2] size (512^3): three solve-loop cycles of the Ax Laplace problem with every
+    large-level path live (two-sweep launches, sweep+residual, correction folded into the first
+    post-smoothing launch, metric in the last) against the same cycles with the separate
+    prolongation / metric passes (NDSM_HIP_NO_TRACK): same du history and same bits; the Dirichlet
+    faces are never written; du falls monotonically at the V-cycle's rate."""
+    import bench
+    n = 512
+    mesh, u0 = bench.boundary_problem(n)
+    out = []
+    for notrack in (False, True):
+        if notrack:
+            os.environ["NDSM_HIP_NO_TRACK"] = "1"
+        else:
+            os.environ.pop("NDSM_HIP_NO_TRACK", None)
+        try:
+            S = hip.MGSolver([n, n, n], mesh, "NDDNDD")
+            S.zero_rhs()
+            S.upload(1, hip.BUF_U, u0)
+            ie, du, nc, h = S.solve(vc_tol=0.0, nmax=3, hist_len=8)
+            out.append((list(h), S.download(1, hip.BUF_U)))
+            S.close()
+        finally:
+            os.environ.pop("NDSM_HIP_NO_TRACK", None)
+    (h1, a), (h2, b) = out
+    assert h1 == h2 and len(h1) == 3
+    assert np.array_equal(a, b)
+    assert h1[1] < 0.3 * h1[0] and h1[2] < 0.3 * h1[1], h1
+    assert np.array_equal(a[:, 0, :], u0[:, 0, :]) and np.array_equal(a[:, -1, :], u0[:, -1, :])
+    assert np.array_equal(a[0], u0[0]) and np.array_equal(a[-1], u0[-1])
