@@ -146,6 +146,14 @@ int ndsmk_relax3(const ndsmk_grid *g, double *u, double *a, double *b, const dou
                  const ndsmk_xfer *px /* != NULL: u += P uc first */, const double *uc);
 int ndsmk_fetch_fused_metric(double *h_out2);
 
+/* pieces of an overlapped z-slab pass: one fused pass over owned planes [z0, z1) only (u -> uout) */
+int ndsmk_fused_window(const ndsmk_grid *g, const double *u, double *uout, const double *rhs, int nsweeps, int z0,
+                       int z1);
+/* two streams: 1 = later copies / RCCL calls go to the communication stream, 0 = main stream again;
+ * fence(from, to): work enqueued on `from` so far precedes work enqueued on `to` from now on */
+int ndsmk_select_stream(int which);
+int ndsmk_stream_fence(int from, int to);
+
 /* ---- mixed-precision mode (mixed.hip): level 1 as iterative refinement, correction in fp32 ---- */
 /* unew = u + e ; ezero = 0 ; r = (float)(rhs - L unew) ; h_out2 = (max|e|, sum|e|), blocking.
  * e == NULL: r = residual of u, nothing else written.  rhs == NULL: zero right-hand side. */

@@ -15,7 +15,9 @@ struct Runtime {
   int device = -1;
   int ncu = 256;  // compute units of the device (MI355X: 256)
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t comm = nullptr;   // halo traffic that overlaps kernels of the main stream (z-slab worlds)
+  bool on_comm = false;         // enqueue copies / RCCL calls on `comm` for now (ndsmk_select_stream)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evx = nullptr;
   char err[512] = "no error";
 };
 
@@ -26,7 +28,7 @@ std::mutex g_mu;
 
 namespace ndsm {
 
-hipStream_t stream() { return g_rt.stream; }
+hipStream_t stream() { return g_rt.on_comm ? g_rt.comm : g_rt.stream; }
 bool ready() { return g_rt.up; }
 int cu_count() { return g_rt.ncu > 0 ? g_rt.ncu : 256; }
 
@@ -68,6 +70,8 @@ int ndsmk_init(int device) {
   NDSM_CHECK_ARG(device < n);
   if (g_rt.up) {  // re-target: drop the old stream
     (void)hipStreamDestroy(g_rt.stream);
+    (void)hipStreamDestroy(g_rt.comm);
+    (void)hipEventDestroy(g_rt.evx);
     (void)hipEventDestroy(g_rt.ev0);
     (void)hipEventDestroy(g_rt.ev1);
     g_rt.up = false;
@@ -78,6 +82,13 @@ int ndsmk_init(int device) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return ndsm::fail(NDSMK_ENODEV, "device is not gfx950 (this library carries MI355X code objects only)", __FILE__, __LINE__);
   NDSM_HIP(hipStreamCreateWithFlags(&g_rt.stream, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0;  // numerically lower = higher priority: halo messages should not queue behind a full grid
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    NDSM_HIP(hipStreamCreateWithPriority(&g_rt.comm, hipStreamNonBlocking, hi));
+  }
+  NDSM_HIP(hipEventCreateWithFlags(&g_rt.evx, hipEventDisableTiming));
+  g_rt.on_comm = false;
   NDSM_HIP(hipEventCreate(&g_rt.ev0));
   NDSM_HIP(hipEventCreate(&g_rt.ev1));
   g_rt.device = device;
@@ -90,7 +101,10 @@ int ndsmk_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_rt.up) return 0;
   (void)hipStreamSynchronize(g_rt.stream);
+  (void)hipStreamSynchronize(g_rt.comm);
   (void)hipStreamDestroy(g_rt.stream);
+  (void)hipStreamDestroy(g_rt.comm);
+  (void)hipEventDestroy(g_rt.evx);
   (void)hipEventDestroy(g_rt.ev0);
   (void)hipEventDestroy(g_rt.ev1);
   g_rt = Runtime();
@@ -139,7 +153,7 @@ int ndsmk_d2h(void *h_dst, const void *src, size_t bytes) {
 
 int ndsmk_d2d(void *dst, const void *src, size_t bytes) {
   NDSM_REQUIRE_READY();
-  NDSM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_rt.stream));
+  NDSM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ndsm::stream()));
   return 0;
 }
 
@@ -151,7 +165,25 @@ int ndsmk_fill0(void *p, size_t bytes) {
 
 int ndsmk_sync(void) {
   NDSM_REQUIRE_READY();
+  NDSM_HIP(hipStreamSynchronize(g_rt.comm));
   NDSM_HIP(hipStreamSynchronize(g_rt.stream));
+  return 0;
+}
+
+// Two streams, one enqueueing thread.  which = 1: device copies and RCCL calls issued from now on
+// go to the communication stream; 0: back to the main stream (kernels are always launched while
+// 0 is selected).  ndsmk_stream_fence(from, to): everything enqueued on `from` so far happens
+// before anything enqueued on `to` from now on (0 = main, 1 = communication).
+int ndsmk_select_stream(int which) {
+  NDSM_REQUIRE_READY();
+  g_rt.on_comm = which != 0;
+  return 0;
+}
+int ndsmk_stream_fence(int from, int to) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG((from == 0 || from == 1) && (to == 0 || to == 1) && from != to);
+  NDSM_HIP(hipEventRecord(g_rt.evx, from ? g_rt.comm : g_rt.stream));
+  NDSM_HIP(hipStreamWaitEvent(to ? g_rt.comm : g_rt.stream, g_rt.evx, 0));
   return 0;
 }
 

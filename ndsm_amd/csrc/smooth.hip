@@ -293,3 +293,22 @@ extern "C" int ndsmk_fetch_fused_metric(double *h_out2) {
   NDSM_REQUIRE_READY();
   return ndsm::fetch_fused_metric(h_out2);
 }
+
+// One out-of-place fused pass (nsweeps = 1 or 2) over the owned planes [z0, z1) of a z-slab only:
+// the pieces of a pass whose halo exchange overlaps its interior (ndsmh_world).  u is read
+// (z0 - 2 nsweeps .. z1 + 2 nsweeps must be valid planes), uout written on [z0, z1).
+extern "C" int ndsmk_fused_window(const ndsmk_grid *gp, const double *u, double *uout, const double *rhs, int nsweeps,
+                                  int z0, int z1) {
+  NDSM_REQUIRE_READY();
+  ndsmk_grid g = *gp;
+  NDSM_CHECK_ARG(g.ndim == 3 && (nsweeps == 1 || nsweeps == 2) && z0 >= g.zown0 && z1 <= g.zown1 && z0 < z1);
+  g.zown0 = z0;
+  g.zown1 = z1;
+  int ndone = 0;
+  int rc = ndsm::launch_rbgs3_fused(g, u, uout, rhs, nsweeps, true, &ndone, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr);
+  if (rc) return rc;
+  if (ndone != nsweeps)
+    return ndsm::fail(NDSMK_EARG, "fused smoother: this window / sweep count is not covered", __FILE__, __LINE__);
+  return 0;
+}

@@ -828,7 +828,8 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   *sweeps_done = 0;
   if (res_done) *res_done = 0;
   if (met_done) *met_done = 0;
-  if (!uout || g.ndim != 3 || (g.n[0] & 1) || g.n[0] < 16 || g.n[1] < 16 || g.zown1 - g.zown0 < 8) return 0;
+  if (!uout || g.ndim != 3 || (g.n[0] & 1) || g.n[0] < 16 || g.n[1] < 16 || g.zown1 - g.zown0 < (force ? 1 : 8))
+    return 0;
   // a z-streaming workgroup walks >= 16 planes serially: with fewer than ~one
   // workgroup per CU the sweep is latency bound and the two colour passes win
   const int64_t npts = (int64_t)g.n[0] * g.n[1] * (g.zown1 - g.zown0);

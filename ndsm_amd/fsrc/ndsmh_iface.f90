@@ -152,6 +152,26 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_fused_window(g, u, uout, rhs, nsweeps, z0, z1) bind(c, name="ndsmk_fused_window") result(rc)
+      import :: ndsmk_grid, c_ptr, c_int
+      type(ndsmk_grid), intent(in) :: g
+      type(c_ptr), value :: u, uout, rhs
+      integer(c_int), value :: nsweeps, z0, z1
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_select_stream(which) bind(c, name="ndsmk_select_stream") result(rc)
+      import :: c_int
+      integer(c_int), value :: which
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_stream_fence(from, to) bind(c, name="ndsmk_stream_fence") result(rc)
+      import :: c_int
+      integer(c_int), value :: from, to
+      integer(c_int) :: rc
+    end function
+
     function ndsmk_update_residual_f32(g, u, unew, rhs, e, ezero, r, h_out2) &
         bind(c, name="ndsmk_update_residual_f32") result(rc)
       import :: ndsmk_grid, c_ptr, c_int, c_double

@@ -25,7 +25,7 @@ module ndsmh_mg
   private
 
   public :: mg_solver, mg_create, mg_destroy, mg_vcycle, mg_solve
-  public :: mg_mixed_applies
+  public :: mg_mixed_applies, mg_relax_window, mg_swap_u
   public :: mg_set_u, mg_set_rhs, mg_get_u, mg_zero_rhs, mg_level_ptr, mg_op, mg_read_info
   public :: mg_mark_rhs_set
   public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
@@ -579,6 +579,23 @@ contains
     end do
     rc = 0
   end function
+
+  ! z-slab level 1, pieces of a pass whose halo exchange overlaps its interior: one fused pass
+  ! (n = 1 or 2 sweeps) over the owned LOCAL planes [z0, z1) only, u -> ualt; mg_swap_u when all
+  ! pieces of the pass are enqueued
+  function mg_relax_window(s, n, z0, z1) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer, intent(in) :: n, z0, z1
+    integer(c_int) :: rc
+    rc = ndsmk_fused_window(s%lev(1)%g, s%dl(1)%u, s%dl(1)%ualt, rhs_of(s, 1), int(n, c_int), int(z0, c_int), &
+                            int(z1, c_int))
+  end function
+
+  subroutine mg_swap_u(s)
+    type(mg_solver), intent(inout) :: s
+    type(c_ptr) :: tmp
+    tmp = s%dl(1)%u; s%dl(1)%u = s%dl(1)%ualt; s%dl(1)%ualt = tmp
+  end subroutine
 
   ! z-slab level 1: restrict the slab's residual into its window of coarse planes
   ! [ck0, ck1) of cbuf (the planes are shipped to rank 0 by the caller)

@@ -466,6 +466,27 @@ contains
     w%ghost_depth = depth
   end function
 
+  ! May a pass with exchange depth d run its interior while the halo travels?  More than one rank,
+  ! every local slab thick enough to have an interior worth a launch, not switched off
+  ! (NDSM_HIP_OVERLAP=0).
+  function overlap_ok(w, d) result(ok)
+    type(mg_world), intent(in) :: w
+    integer, intent(in) :: d
+    logical :: ok
+    integer :: i, st
+    character(len=8) :: env
+    ok = .false.
+    if (w%nranks < 2) return
+    call get_environment_variable("NDSM_HIP_OVERLAP", env, status=st)
+    if (st == 0) then
+      if (env(1:1) == '0') return
+    end if
+    do i = 1, w%nlocal
+      if (w%loc(i)%sl%z1 - w%loc(i)%sl%z0 - 2 * d < 8) return
+    end do
+    ok = .true.
+  end function
+
   ! nsweeps sweeps of every local slab.  A sweep consumes two ghost planes per side (red needs
   ! black of the neighbour plane, black needs that red), so a halo exchange of depth 4 feeds a
   ! two-sweep pass of the temporally blocked kernel: half the messages, half the passes over HBM.
@@ -475,7 +496,7 @@ contains
     integer, intent(in) :: nsweeps
     logical, intent(in), optional :: with_res
     integer(c_int) :: rc
-    integer :: left, n, i
+    integer :: left, n, i, d
     logical :: res, two_ok
     rc = 0
     res = .false.
@@ -489,6 +510,29 @@ contains
         rc = need_ghosts(w, 3); if (rc /= 0) return
         do i = 1, w%nlocal
           rc = mg_op(w%loc(i), MG_OP_RELAX_RES_FUSED, 1, 1); if (rc /= 0) return
+        end do
+      else if (w%ghost_depth < 2 * n .and. overlap_ok(w, 2 * n)) then
+        ! the halo exchange of this pass on the communication stream, the planes that do not need
+        ! it meanwhile, the 2n planes next to each neighbour once it has arrived (out of place:
+        ! all three launches read u and write disjoint planes of its partner)
+        d = 2 * n
+        rc = ndsmk_stream_fence(0_c_int, 1_c_int); if (rc /= 0) return
+        rc = ndsmk_select_stream(1_c_int); if (rc /= 0) return
+        rc = exchange(w, MG_BUF_U, d)
+        i = ndsmk_select_stream(0_c_int)
+        if (rc /= 0) return
+        do i = 1, w%nlocal
+          associate (s => w%loc(i))
+            rc = mg_relax_window(s, n, int(s%lev(1)%g%zown0) + d, int(s%lev(1)%g%zown1) - d); if (rc /= 0) return
+          end associate
+        end do
+        rc = ndsmk_stream_fence(1_c_int, 0_c_int); if (rc /= 0) return
+        do i = 1, w%nlocal
+          associate (s => w%loc(i))
+            rc = mg_relax_window(s, n, int(s%lev(1)%g%zown0), int(s%lev(1)%g%zown0) + d); if (rc /= 0) return
+            rc = mg_relax_window(s, n, int(s%lev(1)%g%zown1) - d, int(s%lev(1)%g%zown1)); if (rc /= 0) return
+            call mg_swap_u(s)
+          end associate
         end do
       else
         rc = need_ghosts(w, 2 * n); if (rc /= 0) return
