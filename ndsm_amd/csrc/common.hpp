@@ -24,7 +24,10 @@ constexpr int kWave = 64;   // CDNA wavefront
 #define NDSM_HIP(call)                                                               \
   do {                                                                               \
     hipError_t e_ = (call);                                                          \
-    if (e_ != hipSuccess) return ndsm::fail((int)e_, hipGetErrorString(e_), __FILE__, __LINE__); \
+    if (e_ != hipSuccess) {                                                          \
+      (void)hipGetLastError(); /* do not leave it sticky for the next launch check */ \
+      return ndsm::fail((int)e_, hipGetErrorString(e_), __FILE__, __LINE__);         \
+    }                                                                                \
   } while (0)
 
 #define NDSM_REQUIRE_READY()                                   \

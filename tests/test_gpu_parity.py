@@ -635,3 +635,26 @@ def test_full_size_config3_properties(hip):
     assert h1[1] < 0.3 * h1[0] and h1[2] < 0.3 * h1[1], h1
     assert np.array_equal(a[:, 0, :], u0[:, 0, :]) and np.array_equal(a[:, -1, :], u0[:, -1, :])
     assert np.array_equal(a[0], u0[0]) and np.array_equal(a[-1], u0[-1])
+
+
+@pytest.mark.gpu
+def test_out_of_memory_is_a_clean_error(hip):
+    """a hierarchy that cannot fit in HBM (2048^3: 64 GiB per level-1 array) fails with a device error
+    code >= 9001 ... (the reference would abort the process in ALLOCATE); nothing leaks into the
+    next call: a small solve right after it still returns the oracle's bits"""
+    n = 2048
+    mesh = [np.linspace(0, 1, n)] * 3
+    with pytest.raises(hip.NdsmHipError):
+        hip.MGSolver([n, n, n], mesh, "NDDNDD")
+    ns = [22, 22, 22]
+    m = uniform_mesh(ns)
+    u, rhs = rand_field((22, 22, 22), 1), rand_field((22, 22, 22), 2)
+    S = hip.MGSolver(ns, m, "NDDNDD")
+    S.upload(1, hip.BUF_U, u)
+    S.upload(1, hip.BUF_RHS, rhs)
+    S.vcycle(1)
+    a = S.download(1, hip.BUF_U)
+    S.upload(1, hip.BUF_U, u)
+    S.vcycle(1)
+    assert np.array_equal(a, S.download(1, hip.BUF_U))
+    S.close()
