@@ -658,3 +658,32 @@ def test_out_of_memory_is_a_clean_error(hip):
     S.vcycle(1)
     assert np.array_equal(a, S.download(1, hip.BUF_U))
     S.close()
+
+
+@pytest.mark.gpu
+def test_argument_errors_are_reported_not_fatal(hip):
+    """bad arguments come back as error codes / exceptions (the reference STOPs the process on its
+    internal asserts, ndsm_root.f90:317-455): unknown BC letter, a dimension below the 4 points one
+    grid needs, an op on a level that does not exist, a forced fused sweep on a shape it cannot take"""
+    ns = [24, 24, 24]
+    m = uniform_mesh(ns)
+    with pytest.raises(hip.NdsmHipError):
+        hip.MGSolver(ns, m, "NDDNDX")
+    with pytest.raises(hip.NdsmHipError):
+        hip.MGSolver([24, 3, 24], uniform_mesh([24, 3, 24]), "NDDNDD")
+    S = hip.MGSolver(ns, m, "NDDNDD")
+    with pytest.raises(hip.NdsmHipError):
+        S.op(hip.OP_RELAX, S.ngrids + 1, 1)
+    S.close()
+    S = hip.MGSolver([23, 24, 24], uniform_mesh([23, 24, 24]), "NDDNDD")     # odd nx: no x-pairs
+    with pytest.raises(hip.NdsmHipError):
+        S.op(hip.OP_RELAX_FUSED, 1, 1)
+    S.upload(1, hip.BUF_U, rand_field((24, 24, 23), 3))
+    S.op(hip.OP_RELAX, 1, 1)                                                 # the two-pass kernel takes it
+    S.close()
+    # the reference's only input check: fewer than two points -> ierr = 1, nothing else touched
+    import ndsm_amd
+    x = np.linspace(0, 1, 1)
+    b = np.zeros((3, 1, 1, 1))
+    ierr, A, B = ndsm_amd.vector_potential(x, x, x, b)
+    assert ierr == 1
