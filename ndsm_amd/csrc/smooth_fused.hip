@@ -149,7 +149,10 @@ struct Slot {
 // workgroup forms the z-interpolated coarse plane of its tile ONCE (one or two coarse points per
 // thread, their values of the two bracketing coarse planes rolling through registers) and
 // parks it in LDS; each fine point then needs four LDS reads and nine flops.
-template <typename T, int S, int TXH, int TYH, int NT, int WPS, bool RHS0, int MODE>
+// LVL1 changes nothing but the kernel's name: launches on levels of >= 64 M points get a symbol of
+// their own, so that a rocprofv3 --stats summary does not average the level-1 launches (the
+// ones bench.py's roofline line is quoted on) with the much shorter ones of the coarser levels.
+template <typename T, int S, int TXH, int TYH, int NT, int WPS, bool RHS0, int MODE, bool LVL1>
 __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u, T *__restrict__ uout,
                                                          const T *__restrict__ rhs, T *__restrict__ rout,
                                                          const T *__restrict__ prev, double *__restrict__ part,
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
           const bool inz = pr >= g.lb[2] && pr <= g.ub[2];
           d2 rr;
           rr.x = rr.y = 0.0;
-          if (!RHS0) rr = rw[RHS0 ? 0 : s][RHS0 ? 0 : NST];
+          if (!RHS0) rr = rw[RHS0 ? 0 : s][(RHS0 || !RES) ? 0 : NST];
           const T v0 = (xl0 + cc.y) * gw0 + (vl.x + vh.x) * gw1 + (wl.x + wh.x) * gw2 - rr.x - cc.x * gwc;
           const T v1 = (cc.x + xh1) * gw0 + (vl.y + vh.y) * gw1 + (wl.y + wh.y) * gw2 - rr.y - cc.y * gwc;
           d2 res;
@@ -717,7 +720,7 @@ int met_scratch(size_t nblk, double **part, double **out2) {
   return 0;
 }
 
-template <typename T, int S, int TXH, int TYH, int NT, int WPS, int MODE = 0>
+template <typename T, int S, int TXH, int TYH, int NT, int WPS, int MODE = 0, bool LVL1 = false>
 int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int target_wgs, T *rout = nullptr,
                const T *prev = nullptr, const ProlArgs *prol = nullptr) {
   constexpr bool RES = MODE == 1;
@@ -733,16 +736,16 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
   static bool attr_set[2] = {false, false};
   static int wgs_per_cu[2] = {1, 1};
   const int v = rhs ? 0 : 1;
-  const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE>)
-                         : reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE>);
+  const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1>)
+                         : reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1>);
   if (!attr_set[v]) {
     NDSM_HIP(hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int occ = 1;
     if (rhs)
-      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE>, NT,
+      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1>, NT,
                                                             lds_bytes));
     else
-      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE>, NT,
+      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1>, NT,
                                                             lds_bytes));
     wgs_per_cu[v] = occ > 0 ? occ : 1;
     attr_set[v] = true;
@@ -783,12 +786,12 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
     if (int rc = met_scratch((size_t)nblk, &part, &out2)) return rc;
   }
   if (rhs)
-    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE>), dim3(nblk), dim3(NT), lds_bytes,
+    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1>), dim3(nblk), dim3(NT), lds_bytes,
                        ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl, pa);
   else  // the level's rhs is identically zero (level 1 of NDSM's Laplace problems,
         // ndsm_vector_potential.f90:640-641): x - 0.0 == x exactly, so the variant that never
         // loads rhs returns the same bits with 8 B/LUP less traffic
-    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE>), dim3(nblk), dim3(NT), lds_bytes,
+    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1>), dim3(nblk), dim3(NT), lds_bytes,
                        ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl, pa);
   NDSM_LAUNCH_CHECK();
   if (MODE == 2) {
@@ -887,7 +890,10 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
     switch (cfg[0]) {
       case 3: rc = launch_cfg<T, 2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;
       case 5: rc = launch_cfg<T, 2, 72, 28, 512, 4>(g, u, uout, rhs, tgt); break;
-      default: rc = launch_cfg<T, 2, 136, 30, 1024, 4>(g, u, uout, rhs, tgt); break;
+      default:
+        rc = big ? (launch_cfg<T, 2, 136, 30, 1024, 4, 0, true>(g, u, uout, rhs, tgt))
+                 : (launch_cfg<T, 2, 136, 30, 1024, 4>(g, u, uout, rhs, tgt));
+        break;
     }
     if (rc) return rc;
     *sweeps_done = 2;
