@@ -111,6 +111,56 @@ def slab_window_problem(n3, sl):
     return [x, y, z], u, a
 
 
+def slab_self_check(_lib, L, dist, rank, world):
+    """The distributed path against the single-GPU solver on a problem small enough to gather:
+    level 1 of a 128 x 128 x 32N box cut into N z-slabs (RCCL halo exchange, the same code path as
+    the timed workload, two distributed levels forced), 2 V-cycles, owned planes gathered to rank 0
+    over gloo and compared BIT FOR BIT with the same V-cycles of one MGSolver.  Returns a string."""
+    import torch
+    ns = [128, 128, 32 * world]
+    dx = 1.0 / (ns[0] - 1)
+    mesh = [np.arange(n) * dx for n in ns]
+    rng = np.random.default_rng(2112)
+    u = rng.uniform(-1, 1, tuple(ns[::-1]))
+    rhs = rng.uniform(-1, 1, tuple(ns[::-1]))
+    old = os.environ.get("NDSM_HIP_DIST_LEVELS")
+    os.environ["NDSM_HIP_DIST_LEVELS"] = "2"
+    try:
+        W = _lib.World(ns, mesh, "NDDNDD", world, rank, lib=L)
+    finally:
+        if old is None:
+            os.environ.pop("NDSM_HIP_DIST_LEVELS", None)
+        else:
+            os.environ["NDSM_HIP_DIST_LEVELS"] = old
+    sl = W.slabs[0]
+    a, b = max(sl["k0"], 0), min(sl["k0"] + sl["nloc"], ns[2])
+    W.upload_window(1, _lib.BUF_U, u[a:b], a)
+    W.upload_window(1, _lib.BUF_RHS, rhs[a:b], a)
+    W.vcycle(2)
+    mine = np.empty((sl["z1"] - sl["z0"], ns[1], ns[0]))
+    _lib._check(L.ndsm_hip_world_download(W.h, 1, _lib.BUF_U, mine.ctypes.data_as(_lib._dp)), "download", L)
+    levels = W.dist_levels
+    W.close()
+    parts = [None] * world
+    dist.all_gather_object(parts, (sl["z0"], sl["z1"], mine))
+    if rank != 0:
+        return ""
+    got = np.empty_like(u)
+    for z0, z1, p in parts:
+        got[z0:z1] = p
+    S = _lib.MGSolver(ns, mesh, "NDDNDD", lib=L)
+    S.upload(1, _lib.BUF_U, u)
+    S.upload(1, _lib.BUF_RHS, rhs)
+    S.vcycle(2)
+    want = S.download(1, _lib.BUF_U)
+    S.close()
+    nd = int((got != want).sum())
+    tag = f"{ns[0]}x{ns[1]}x{ns[2]} in {world} z-slabs over RCCL, {levels} distributed levels, 2 V-cycles"
+    if nd == 0:
+        return "bit-identical to the single-GPU solver (" + tag + ")"
+    return f"MISMATCH: {nd} points differ, max {np.abs(got - want).max():.3e} (" + tag + ")"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +190,7 @@ def main():
 
     dist = None
     rccl_ok, rccl_err, slab_mode = True, "", False
+    slab_check = None
     if world > 1:
         import faulthandler
         faulthandler.dump_traceback_later(600, exit=True)   # a wedged collective must not hang the node
@@ -213,6 +264,10 @@ def main():
                            "pass), levels>=2 on rank 0")
             scaling = "strong"
             slab_mode = True
+            try:
+                slab_check = slab_self_check(_lib, L, dist, rank, world)
+            except Exception as exc:  # noqa: BLE001
+                slab_check = f"self-check could not run: {type(exc).__name__}: {exc}"
         else:
             # the distributed path could not be brought up on this node: say so and measure
             # independent replicas of the 1-GPU workload instead of reporting nothing
@@ -335,6 +390,8 @@ def main():
                              "launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/traffic_latest.json"},
         "rocm_stack": _lib.bound_libs(L),
     }
+    if slab_check is not None:
+        out["slab_check"] = slab_check
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
