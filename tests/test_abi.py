@@ -34,6 +34,15 @@ def test_header_symbols_exported(lib):
     assert not missing, missing
 
 
+def test_nothing_else_is_exported():
+    """the shared object's dynamic symbol table is exactly the header (linker version script): no
+    Fortran runtime, no internal kernel layer - it can share a process with any other flang library"""
+    import ndsm_amd
+    out = subprocess.check_output(["nm", "-D", "--defined-only", ndsm_amd.lib_path()], text=True)
+    live = sorted(l.split()[-1] for l in out.splitlines() if re.search(r" [TDB] ", l))
+    assert live == declared_functions()
+
+
 def test_reference_symbol_set_is_covered(lib):
     """every C symbol of the reference's ndsmf.so (fortran/ndsm_python_wrapper.f90) exists here"""
     ref_symbols = ["ndsm_vector_solve", "get_iopt_len", "get_iopt_ierr", "get_iopt_ms", "get_iopt_ncycles",
@@ -54,7 +63,7 @@ def test_getters_match_reference_values(lib):
     want = dict(get_iopt_len=16, get_iopt_ierr=16, get_iopt_ms=0, get_iopt_ncycles=1, get_iopt_debug=5,
                 get_iopt_dumax=6, get_iopt_iopt_nmaxex=7, get_iopt_true=1, get_iopt_false=0, get_ropt_tim=2,
                 get_ropt_vtol=0, get_ropt_ctol=1, get_iopt_fail3d=8, get_iopt_ngrids=9, get_iopt_ncyc_out=10,
-                get_ropt_dulast=3)
+                get_iopt_prec=11, get_ropt_dulast=3)
     for name, val in want.items():
         assert getattr(lib, name)() == val, name
     ref_so = os.path.join(ROOT, "oracle", "_ref", "ndsmf.so")
