@@ -687,3 +687,65 @@ def test_argument_errors_are_reported_not_fatal(hip):
     b = np.zeros((3, 1, 1, 1))
     ierr, A, B = ndsm_amd.vector_potential(x, x, x, b)
     assert ierr == 1
+
+
+@pytest.mark.gpu
+def test_random_shapes_solve_vs_oracle(hip, port):
+    """seeded random small shapes (8..71 per dimension, odd and even), random D/N face letters, random
+    ms: four solve-loop cycles on the device against the oracle - solution bits, du history, cycle count
+    (scripts/fuzz_shapes.py runs the same with more cases)"""
+    rng = np.random.default_rng(20260101)
+    for c in range(16):
+        ns = [int(rng.integers(8, 72)) for _ in range(3)]
+        bcs = "".join(rng.choice(["D", "N"]) for _ in range(6))
+        if bcs == "NNNNNN":
+            bcs = "NNNNND"
+        ms = int(rng.integers(1, 6))
+        mesh = uniform_mesh(ns)
+        shp = tuple(ns[::-1])
+        u, rhs = rand_field(shp, 100 + c), rand_field(shp, 200 + c)
+        ierr2, u2, du2, h2, nc2, sw = port.solve_bvp(u.copy(), rhs, mesh, bcs, ms=ms, nmax=4, hist_len=8)
+        S = hip.MGSolver(ns, mesh, bcs, ms=ms)
+        S.upload(1, hip.BUF_U, u)
+        S.upload(1, hip.BUF_RHS, rhs)
+        ierr, du, nc, h = S.solve(vc_tol=1e-10, nmax=4, hist_len=8)
+        got = S.download(1, hip.BUF_U)
+        S.close()
+        assert nc == nc2 and list(h) == list(h2[:len(h)]), (ns, bcs, ms)
+        assert np.array_equal(got, u2), (ns, bcs, ms)
+
+
+@pytest.mark.gpu
+def test_random_shapes_fused_launches(hip):
+    """seeded random level shapes (ragged against every tile size), random face letters, 1..5 sweeps, with
+    and without a right-hand side: the forced fused launches (and the sweep+residual launch) return the
+    bits of the two-pass kernels + residual.hip (scripts/fuzz_fused.py)"""
+    rng = np.random.default_rng(20260102)
+    for c in range(20):
+        ns = [2 * int(rng.integers(8, 150)), int(rng.integers(16, 200)), int(rng.integers(8, 120))]
+        bcs = "".join(rng.choice(["D", "N"]) for _ in range(6))
+        if bcs == "NNNNNN":
+            bcs = "DNNNNN"
+        nsw = int(rng.integers(1, 6))
+        lap = bool(rng.integers(0, 2))
+        mesh = uniform_mesh(ns)
+        shp = tuple(ns[::-1])
+        u, rhs = rand_field(shp, 100 + c), rand_field(shp, 200 + c)
+        S = hip.MGSolver(ns, mesh, bcs)
+        if lap:
+            S.zero_rhs()
+        else:
+            S.upload(1, hip.BUF_RHS, rhs)
+        S.upload(1, hip.BUF_U, u)
+        S.op(hip.OP_RELAX_COLOR, 1, nsw)
+        S.op(hip.OP_RESIDUAL, 1)
+        a, ra = S.download(1, hip.BUF_U), S.download(1, hip.BUF_R)
+        S.upload(1, hip.BUF_U, u)
+        S.op(hip.OP_RELAX_FUSED, 1, nsw)
+        assert np.array_equal(a, S.download(1, hip.BUF_U)), (ns, bcs, nsw, lap)
+        S.upload(1, hip.BUF_U, u)
+        S.upload(1, hip.BUF_R, np.full(shp, np.nan))
+        S.op(hip.OP_RELAX_RES_FUSED, 1, nsw)
+        assert np.array_equal(a, S.download(1, hip.BUF_U)), (ns, bcs, nsw, lap)
+        assert np.array_equal(ra, S.download(1, hip.BUF_R)), (ns, bcs, nsw, lap)
+        S.close()
