@@ -749,3 +749,45 @@ def test_random_shapes_fused_launches(hip):
         assert np.array_equal(a, S.download(1, hip.BUF_U)), (ns, bcs, nsw, lap)
         assert np.array_equal(ra, S.download(1, hip.BUF_R)), (ns, bcs, nsw, lap)
         S.close()
+
+
+@pytest.mark.gpu
+def test_random_slab_worlds(hip):
+    """seeded random shapes, 2..8 slabs, 1..3 distributed levels, exchange overlap on or off, random ms and
+    face letters: three solve-loop cycles of the loop-back world return the single-domain solver's du
+    history and bits (scripts/fuzz_world.py)"""
+    rng = np.random.default_rng(20260103)
+    done = 0
+    try:
+        while done < 12:
+            nr = int(rng.integers(2, 9))
+            ns = [2 * int(rng.integers(8, 80)), int(rng.integers(16, 120)), int(rng.integers(16, 60)) * nr]
+            lv = int(rng.integers(1, 4))
+            bcs = "".join(rng.choice(["D", "N"]) for _ in range(6))
+            if bcs == "NNNNNN":
+                bcs = "DNNNNN"
+            ms = int(rng.integers(1, 6))
+            os.environ["NDSM_HIP_DIST_LEVELS"] = str(lv)
+            os.environ["NDSM_HIP_OVERLAP"] = str(int(rng.integers(0, 2)))
+            mesh = uniform_mesh(ns)
+            shp = tuple(ns[::-1])
+            u, rhs = rand_field(shp, 100 + done), rand_field(shp, 200 + done)
+            try:
+                W = hip.World(ns, mesh, bcs, nr, ms=ms)
+            except hip.NdsmHipError:
+                continue          # the shape cannot be cut that way
+            S = hip.MGSolver(ns, mesh, bcs, ms=ms)
+            S.upload(1, hip.BUF_U, u)
+            S.upload(1, hip.BUF_RHS, rhs)
+            W.upload(hip.BUF_U, u)
+            W.upload(hip.BUF_RHS, rhs)
+            r1 = S.solve(vc_tol=1e-10, nmax=3, hist_len=8)
+            r2 = W.solve(vc_tol=1e-10, nmax=3, hist_len=8)
+            assert r1[2] == r2[2] and list(r1[3]) == list(r2[3]), (ns, nr, lv, bcs, ms)
+            assert np.array_equal(S.download(1, hip.BUF_U), W.download(hip.BUF_U)), (ns, nr, lv, bcs, ms)
+            S.close()
+            W.close()
+            done += 1
+    finally:
+        os.environ.pop("NDSM_HIP_DIST_LEVELS", None)
+        os.environ.pop("NDSM_HIP_OVERLAP", None)
