@@ -57,7 +57,7 @@ def boundary_problem(n):
     return [x, y, z], u
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=12.0):
     """Reference smoother (red_black_gauss_3D, ndsm_optimized.f90:40) on this
     box's host cores; falls back to the C port if oracle/_ref is absent."""
     from oracle import Oracle, have_ref, usable_cpus
@@ -74,7 +74,7 @@ def cpu_baseline(seconds_budget=20.0):
         u = orc.relax3d(u, rhs, mesh, "NDDNDD")
         sweeps += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or sweeps >= 200:
+        if el > seconds_budget or sweeps >= 2000:
             break
     # each call copies u once in the ctypes wrapper; time that copy and subtract
     t1 = time.perf_counter()
