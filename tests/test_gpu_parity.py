@@ -791,3 +791,30 @@ def test_random_slab_worlds(hip):
     finally:
         os.environ.pop("NDSM_HIP_DIST_LEVELS", None)
         os.environ.pop("NDSM_HIP_OVERLAP", None)
+
+
+@pytest.mark.gpu
+def test_full_size_config4_loopback(hip):
+    """BASELINE config[3] shape (1024 x 1024 x 512, 4 GiB per array) cut into 8 z-slabs - loop-back world,
+    distributed levels by the default rule (two here), halo exchange behind the interior planes - against
+    the single-domain solver: one V-cycle, bit for bit."""
+    ns = [1024, 1024, 512]
+    dx = 1.0 / (ns[0] - 1)
+    mesh = [np.arange(n) * dx for n in ns]
+    rng = np.random.default_rng(11)
+    az, by, cx = rng.uniform(-1, 1, ns[2]), rng.uniform(-1, 1, ns[1]), rng.uniform(-1, 1, ns[0])
+    u = az[:, None, None] * by[None, :, None] + cx[None, None, :]
+    W = hip.World(ns, mesh, "NDDNDD", 8)
+    assert W.dist_levels == 2
+    W.upload(hip.BUF_U, u)
+    W.zero_rhs()
+    W.vcycle(1)
+    b = W.download(hip.BUF_U)
+    W.close()
+    S = hip.MGSolver(ns, mesh, "NDDNDD")
+    S.upload(1, hip.BUF_U, u)
+    S.zero_rhs()
+    S.vcycle(1)
+    a = S.download(1, hip.BUF_U)
+    S.close()
+    assert np.array_equal(a, b)
