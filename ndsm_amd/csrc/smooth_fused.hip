@@ -1,32 +1,38 @@
-// Fused red+black Gauss-Seidel sweep: ONE launch reads u (and rhs) once and
-// writes the swept field once (OUT OF PLACE: workgroups read each other's halo
-// from the input array, so the input must stay intact for the whole launch;
-// the caller ping-pongs two arrays) - the 24 B/LUP the roofline is priced on - where
-// the two colour passes of smooth.hip move ~48 B/LUP with half-used lines.
+// Fused red+black Gauss-Seidel sweeps: ONE launch reads u (and rhs) once, performs S full sweeps
+// (S = 1 or 2, temporal blocking) and writes the swept field once - OUT OF PLACE: workgroups read
+// each other's halo from the input array, so the input must stay intact for the whole launch and
+// the caller ping-pongs (or rotates) arrays.  The two colour passes of smooth.hip move ~48 B/LUP
+// with half-used lines; this moves ~24/S B/LUP plus halo.
 //
-// Same arithmetic as rbgs3_color (ndsm_optimized.f90:103-167): a black point
-// only reads red neighbours of the SAME sweep and a red point only reads black
-// neighbours of the PREVIOUS state, so any schedule that respects those two
-// dependencies gives bit-identical results.  Schedule used here (per workgroup):
+// Same arithmetic as rbgs3_color (ndsm_optimized.f90:103-167): a black point only reads red
+// neighbours of the SAME sweep and a red point only reads black neighbours of the PREVIOUS state,
+// so any schedule that respects those two dependencies gives bit-identical results.  Schedule
+// used here (per workgroup; the comment on rbgs3_fused_k has the pipeline in detail):
 //
-//   * an (x,y) tile of TXH x TYH points, of which the inner TXI x TYI are
-//     owned (written back) and a 2-deep ring is halo: ring 1 is red-updated
-//     redundantly so that owned black points see updated red neighbours;
-//   * the tile is streamed through a z chunk [zs, ze) as a 2-stage pipeline:
-//     iteration k does  stage 0: red   update of plane k
-//                       stage 1: black update of plane k-1, then stores it.
-//     z neighbours live in the owning thread's registers, the in-plane
-//     neighbours in two LDS planes (R_k and R_{k-1});
-//   * every thread owns x-PAIRS (16-byte aligned double2): each global load /
-//     store is 16 B per lane, rows are contiguous, and every pair holds exactly
-//     one red and one black point per plane - no divergence between colours;
-//   * plane k+2 (and its rhs) is requested before plane k is computed, so one
-//     whole plane of loads per workgroup is always in flight;
-//   * work items (tile, chunk) are laid out so that the y-neighbouring tiles,
-//     which share halo rows, sit on the same XCD (blockIdx % 8) and hit its L2.
+//   * an (x,y) tile of TXH x TYH points, of which the inner TXI x TYI are owned (written back) and
+//     a ring as deep as the pipeline is halo, updated redundantly as far as it stays valid;
+//   * the tile is streamed through a z chunk [zs, ze) as a 2S-stage pipeline skewed along z:
+//     iteration k runs stage t (even red, odd black) on plane k - t.  The z+1 neighbour comes
+//     from the register the previous stage just produced, everything else from LDS planes kept
+//     element-planar (all "element 0" of the x-pairs, then all "element 1") so that a stage's
+//     accesses are conflict free;
+//   * every thread owns two x-PAIRS (16-byte aligned): each global load / store is 16 B per lane,
+//     rows are contiguous, and a pair holds exactly one red and one black point per plane - no
+//     divergence between colours;
+//   * plane k+2 (and its rhs) is requested before plane k is computed; global stores are issued
+//     right after the wait that consumes those loads (a vmcnt wait also waits for anything issued
+//     since the load it is meant for);
+//   * work items (tile, chunk) are laid out so that the y-neighbouring tiles, which share halo
+//     rows, sit on the same XCD (blockIdx % 8) and hit its L2; the number of z chunks minimises
+//     rounds of workgroups x planes walked.
 //
-// Requirements of this path (otherwise smooth.hip runs): nx even, n >= 8 in
-// every dimension, no z-slab ghosts inside the chunk logic other than k0/nzg.
+// Modes (one template parameter): 0 plain, 1 + residual of the result as one more stage,
+// 2 + convergence metric against the iterate the V-cycle started from, 3 + coarse-grid
+// correction added to every plane as it is loaded.  T = double is the reference's arithmetic;
+// T = float serves the correction equation of the mixed-precision mode.
+//
+// Requirements of this path (otherwise smooth.hip runs): 3-D, nx even, >= 16 x 16 points per
+// plane; z-slabs enter through k0 / nzg / zown0 / zown1 of the grid descriptor.
 #include "common.hpp"
 
 #include <cstdlib>
