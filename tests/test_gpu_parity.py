@@ -818,3 +818,35 @@ def test_full_size_config4_loopback(hip):
     a = S.download(1, hip.BUF_U)
     S.close()
     assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_baseline_config0_three_level_cycle(hip, port):
+    """BASELINE config[0]: 64^3 Poisson, 3-level V-cycle (additive option slot get_iopt_ngrids; the
+    coarsest grid is then 16^3 = 4096 points, beyond the single-workgroup coarse kernel, so the
+    host-driven exact-solve loop runs): whole solve against the oracle with the same level cap -
+    solution bits, du history, V-cycle count, coarse sweep count."""
+    ns = [64, 64, 64]
+    mesh = uniform_mesh(ns)
+    us, rhs = manufactured_poisson(mesh, "NDDNDD")
+    ierr, u, du, hist, nc = hip.poisson_solve(np.zeros_like(us), rhs, mesh, "NDDNDD", ngrids=3, hist_len=64)
+    ierr2, u2, du2, hist2, nc2, sw = port.solve_bvp(np.zeros_like(us), rhs, mesh, "NDDNDD", ngrids=3, hist_len=64)
+    assert ierr == ierr2 == 0 and nc == nc2
+    assert list(hist) == list(hist2[:nc2])
+    assert np.array_equal(u, u2)
+
+
+@pytest.mark.gpu
+def test_baseline_config1_six_level_cycle(hip):
+    """BASELINE config[1]: 256^3 Poisson fp64, 6-level V-cycle (coarsest 8^3): converges at the V-cycle's
+    rate to the manufactured solution's O(h^2) error, and the level cap is honoured"""
+    ns = [256, 256, 256]
+    mesh = uniform_mesh(ns)
+    us, rhs = manufactured_poisson(mesh, "NDDNDD")
+    S = hip.MGSolver(ns, mesh, "NDDNDD", ngrids=6)
+    assert S.ngrids == 6 and tuple(S.shapes[-1]) == (8, 8, 8)
+    S.close()
+    ierr, u, du, hist, nc = hip.poisson_solve(np.zeros_like(us), rhs, mesh, "NDDNDD", ngrids=6, hist_len=64)
+    assert ierr == 0 and du < 1e-10 and nc <= 20
+    assert np.abs(u - us).max() < 5e-5
+    assert all(hist[i + 1] < 0.5 * hist[i] for i in range(len(hist) - 1))
