@@ -94,6 +94,54 @@ __global__ __launch_bounds__(1024) void rbgs3_small(double *__restrict__ u, cons
 
 // 2-D colour pass (generic N-D path of the reference specialised to ndim = 2):
 // red = (i+j) even in either index base (ndsm_poisson.f90:499-501).
+// Small 2-D level (<= 4096 points): every sweep of a relax call - both colour passes and, on
+// all-Neumann problems, the mean shift after each sweep (ndsm_poisson.f90:534-547) - in ONE
+// single-workgroup launch.  The six face solves of the vector potential are pure dispatch
+// latency on their coarse levels (5 of the 8 levels of a 512^2 face); this takes ~30 launches
+// per level and V-cycle down to 3.  Same update expressions as rbgs2_color; the mean is a fixed
+// tree over the workgroup (the reference's own sum is an unordered OpenMP reduction).
+__global__ __launch_bounds__(1024) void rbgs2_small(double *__restrict__ u, const double *__restrict__ rhs,
+                                                    ndsmk_grid g, int nsweeps) {
+  __shared__ double red[16];
+  const int nx = g.n[0], ny = g.n[1];
+  const int n = nx * ny;
+  const int mx = g.ub[0] - g.lb[0] + 1, my = g.ub[1] - g.lb[1] + 1;
+  const int half = (mx + 1) / 2;
+  const int total = half * my;
+  for (int sw = 0; sw < nsweeps; ++sw) {
+    for (int pass = 0; pass < 2; ++pass) {
+      const int par = (g.first_par + pass) & 1;
+      for (int p = threadIdx.x; p < total; p += blockDim.x) {
+        const int t = p % half, j = g.lb[1] + p / half;
+        const int i0 = g.lb[0] + ((((g.lb[0] + j) & 1) != par) ? 1 : 0);
+        const int i = i0 + 2 * t;
+        if (i > g.ub[0]) continue;
+        const int xl = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i - 1);
+        const int xh = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i + 1);
+        const int yl = (j == 0) ? 1 : (j == ny - 1 ? ny - 2 : j - 1);
+        const int yh = (j == 0) ? 1 : (j == ny - 1 ? ny - 2 : j + 1);
+        double un = 0.0;  // ndsm_poisson.f90:603-617
+        un = un + u[xl + nx * j] * g.w[0] + u[xh + nx * j] * g.w[0];
+        un = un + u[i + nx * yl] * g.w[1] + u[i + nx * yh] * g.w[1];
+        u[i + nx * j] = (un - (rhs ? rhs[i + nx * j] : 0.0)) * g.w1;
+      }
+      __syncthreads();
+    }
+    if (g.all_neumann) {
+      double sm = 0.0;
+      for (int p = threadIdx.x; p < n; p += blockDim.x) sm = sm + u[p];
+      for (int o = 32; o > 0; o >>= 1) sm = sm + __shfl_down(sm, o, 64);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sm;
+      __syncthreads();
+      double tot = 0.0;
+      for (int q = 0; q < 16; ++q) tot = tot + red[q];
+      const double mean = tot / (double)n;
+      for (int p = threadIdx.x; p < n; p += blockDim.x) u[p] = u[p] - mean;
+      __syncthreads();
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void rbgs2_color(double *__restrict__ u, const double *__restrict__ rhs,
                                                   ndsmk_grid g, int par) {
   const int nx = g.n[0], ny = g.n[1];
@@ -156,6 +204,16 @@ static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double 
       if (int rc = ndsmk_prolong_add(px, uc, bufs[0])) return rc;
     }
     hipLaunchKernelGGL(rbgs3_small, dim3(1), dim3(1024), 0, s, bufs[0], rhs, g, nsweeps);
+    NDSM_LAUNCH_CHECK();
+    return 0;
+  }
+  // small 2-D level: likewise (incl. the mean shift of all-Neumann problems)
+  if (g.ndim == 2 && variant == 0 && npts <= 4096 && nsweeps > 0) {
+    NDSM_CHECK_ARG(in_place_ok());
+    if (prol_pending) {
+      if (int rc = ndsmk_prolong_add(px, uc, bufs[0])) return rc;
+    }
+    hipLaunchKernelGGL(rbgs2_small, dim3(1), dim3(1024), 0, s, bufs[0], rhs, g, nsweeps);
     NDSM_LAUNCH_CHECK();
     return 0;
   }
