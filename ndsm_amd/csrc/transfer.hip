@@ -48,7 +48,62 @@ __global__ __launch_bounds__(256) void restrict_k(const double *__restrict__ f, 
   const double *cy = x.rw[1] + (size_t)J * x.maxt[1];
   const size_t sy = (size_t)x.nf[0], sz = (size_t)x.nf[0] * (size_t)x.nf[1];
   double fc = 0.0;
-  if (NDIM == 3) {
+  // The tap loops have per-thread trip counts (3-5 per dimension), so the compiler cannot batch
+  // their loads and every tap costs a dependent global-memory latency.  With at most RT taps per
+  // dimension (true for every mesh ratio >= 2) the weights are fetched up front and the loops
+  // are fixed-bound with the taps predicated - same taps, same order, same expressions.
+  constexpr int RT = 6;
+  if (x.maxt[0] <= RT && x.maxt[1] <= RT && (NDIM == 2 || x.maxt[2] <= RT)) {
+    double wx[RT], wy[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      wx[q] = q < ni ? cx[q] : 0.0;
+      wy[q] = q < nj ? cy[q] : 0.0;
+    }
+    if (NDIM == 3) {
+      const int k0 = x.rlo[2][K] - x.f_k0, nk = x.rcnt[2][K];  // first tap as a local fine plane
+      const double *cz = x.rw[2] + (size_t)K * x.maxt[2];
+      for (int kk = 0; kk < nk; ++kk) {
+        const double c2z = cz[kk];
+#pragma unroll
+        for (int jj = 0; jj < RT; ++jj) {
+          if (jj < nj) {
+            const double *row = f + (size_t)i0 + sy * (size_t)(j0 + jj) + sz * (size_t)(k0 + kk);
+            double fr[RT];
+#pragma unroll
+            for (int ii = 0; ii < RT; ++ii) fr[ii] = ii < ni ? row[ii] : 0.0;
+#pragma unroll
+            for (int ii = 0; ii < RT; ++ii) {
+              if (ii < ni) {
+                double w = wx[ii] * x.w2[0];  // 1 * c2 * w2 (ndsm_interp.f90:277-282)
+                w = w * wy[jj] * x.w2[1];
+                w = w * c2z * x.w2[2];
+                fc = fc + w * fr[ii];
+              }
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < RT; ++jj) {
+        if (jj < nj) {
+          const double *row = f + (size_t)i0 + sy * (size_t)(j0 + jj);
+          double fr[RT];
+#pragma unroll
+          for (int ii = 0; ii < RT; ++ii) fr[ii] = ii < ni ? row[ii] : 0.0;
+#pragma unroll
+          for (int ii = 0; ii < RT; ++ii) {
+            if (ii < ni) {
+              double w = wx[ii] * x.w2[0];
+              w = w * wy[jj] * x.w2[1];
+              fc = fc + w * fr[ii];
+            }
+          }
+        }
+      }
+    }
+  } else if (NDIM == 3) {
     const int k0 = x.rlo[2][K] - x.f_k0, nk = x.rcnt[2][K];  // first tap as a local fine plane
     const double *cz = x.rw[2] + (size_t)K * x.maxt[2];
     for (int kk = 0; kk < nk; ++kk) {
