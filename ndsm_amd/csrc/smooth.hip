@@ -60,9 +60,17 @@ __global__ __launch_bounds__(256) void rbgs3_color(double *__restrict__ u, const
 // boundary, so two launches per sweep are pure launch latency; inside a single
 // workgroup __syncthreads() orders the colour passes (global writes of a block are
 // visible to the block after the barrier).  Same update expression as rbgs3_color.
-__global__ __launch_bounds__(1024) void rbgs3_small(double *__restrict__ u, const double *__restrict__ rhs,
+__global__ __launch_bounds__(1024) void rbgs3_small(double *__restrict__ u_g, const double *__restrict__ rhs_g,
                                                     ndsmk_grid g, int nsweeps) {
+  // the whole level (<= 4096 points) and its right-hand side sit in LDS for the duration
+  __shared__ double u[4096], rhs[4096];
   const int nx = g.n[0], ny = g.n[1];
+  const int n = nx * ny * g.n[2];
+  for (int p = threadIdx.x; p < n; p += blockDim.x) {
+    u[p] = u_g[p];
+    rhs[p] = rhs_g ? rhs_g[p] : 0.0;
+  }
+  __syncthreads();
   const int mx = g.ub[0] - g.lb[0] + 1, my = g.ub[1] - g.lb[1] + 1, mz = g.ub[2] - g.lb[2] + 1;
   const int half = (mx + 1) / 2;
   const int total = half * my * mz;
@@ -84,27 +92,32 @@ __global__ __launch_bounds__(1024) void rbgs3_small(double *__restrict__ u, cons
         const double unew = (u[lin3(xh, j, k, nx, ny)] + u[lin3(xl, j, k, nx, ny)]) * g.w[0] +
                             (u[lin3(i, yh, k, nx, ny)] + u[lin3(i, yl, k, nx, ny)]) * g.w[1] +
                             (u[lin3(i, j, zh, nx, ny)] + u[lin3(i, j, zl, nx, ny)]) * g.w[2] -
-                            (rhs ? rhs[lin3(i, j, k, nx, ny)] : 0.0);
+                            rhs[lin3(i, j, k, nx, ny)];
         u[lin3(i, j, k, nx, ny)] = g.w1 * unew;
       }
       __syncthreads();
     }
   }
+  for (int p = threadIdx.x; p < n; p += blockDim.x) u_g[p] = u[p];
 }
 
-// 2-D colour pass (generic N-D path of the reference specialised to ndim = 2):
-// red = (i+j) even in either index base (ndsm_poisson.f90:499-501).
 // Small 2-D level (<= 4096 points): every sweep of a relax call - both colour passes and, on
 // all-Neumann problems, the mean shift after each sweep (ndsm_poisson.f90:534-547) - in ONE
 // single-workgroup launch.  The six face solves of the vector potential are pure dispatch
 // latency on their coarse levels (5 of the 8 levels of a 512^2 face); this takes ~30 launches
 // per level and V-cycle down to 3.  Same update expressions as rbgs2_color; the mean is a fixed
 // tree over the workgroup (the reference's own sum is an unordered OpenMP reduction).
-__global__ __launch_bounds__(1024) void rbgs2_small(double *__restrict__ u, const double *__restrict__ rhs,
+__global__ __launch_bounds__(1024) void rbgs2_small(double *__restrict__ u_g, const double *__restrict__ rhs_g,
                                                     ndsmk_grid g, int nsweeps) {
+  __shared__ double u[4096], rhs[4096];  // the whole level in LDS
   __shared__ double red[16];
   const int nx = g.n[0], ny = g.n[1];
   const int n = nx * ny;
+  for (int p = threadIdx.x; p < n; p += blockDim.x) {
+    u[p] = u_g[p];
+    rhs[p] = rhs_g ? rhs_g[p] : 0.0;
+  }
+  __syncthreads();
   const int mx = g.ub[0] - g.lb[0] + 1, my = g.ub[1] - g.lb[1] + 1;
   const int half = (mx + 1) / 2;
   const int total = half * my;
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(1024) void rbgs2_small(double *__restrict__ u, cons
         double un = 0.0;  // ndsm_poisson.f90:603-617
         un = un + u[xl + nx * j] * g.w[0] + u[xh + nx * j] * g.w[0];
         un = un + u[i + nx * yl] * g.w[1] + u[i + nx * yh] * g.w[1];
-        u[i + nx * j] = (un - (rhs ? rhs[i + nx * j] : 0.0)) * g.w1;
+        u[i + nx * j] = (un - rhs[i + nx * j]) * g.w1;
       }
       __syncthreads();
     }
@@ -140,6 +153,7 @@ __global__ __launch_bounds__(1024) void rbgs2_small(double *__restrict__ u, cons
       __syncthreads();
     }
   }
+  for (int p = threadIdx.x; p < n; p += blockDim.x) u_g[p] = u[p];
 }
 
 __global__ __launch_bounds__(256) void rbgs2_color(double *__restrict__ u, const double *__restrict__ rhs,
