@@ -843,7 +843,7 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   // workgroup per CU the sweep is latency bound and the two colour passes win
   const int64_t npts = (int64_t)g.n[0] * g.n[1] * (g.zown1 - g.zown0);
   const bool slab = g.zown1 - g.zown0 != g.n[2];
-  if (npts < (int64_t)6 * 1024 * 1024 && !slab && !force) return 0;
+  if (npts < (int64_t)2 * 1024 * 1024 && !slab && !force) return 0;
   // Tile choices measured on MI355X (scripts/tune_smoother.py); launch_cfg picks the z chunking.
   int rc;
   const int *cfg = fused_cfg();

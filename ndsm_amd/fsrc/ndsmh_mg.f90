@@ -720,7 +720,7 @@ contains
     if (s%ndim /= 3 .or. s%slab .or. s%ngrids < 2 .or. s%ms < 1) return
     if (s%lev(1)%g%all_neumann /= 0) return
     if (mod(s%lev(1)%n(1), 2) /= 0 .or. any(s%lev(1)%n(1:2) < 16) .or. s%lev(1)%n(3) < 8) return
-    if (s%lev(1)%npts < 6_ik * 1024_ik * 1024_ik) return
+    if (s%lev(1)%npts < 2_ik * 1024_ik * 1024_ik) return
     call get_environment_variable("NDSM_HIP_NO_TRACK", status=st)
     if (st == 0) return
     ok = .true.
