@@ -144,6 +144,9 @@ int ndsm_hip_mg_info(void *handle, int64_t *exact_sweeps, int64_t *unconverged_c
  * ndsm_hip_init(local device) first. */
 int ndsm_hip_dist_unique_id(void *id128);
 int ndsm_hip_dist_init(int rank, int nranks, const void *id128);
+/* destroys the communicator after draining the library's streams; call on every rank once all
+ * worlds are destroyed.  No-op without a communicator. */
+int ndsm_hip_dist_finalize(void);
 
 /* Slab plan for nranks ranks, 12 ints per rank: rank, z0, z1 (owned fine planes), g (ghost
  * depth), nloc (= z1 - z0 + 2 g), k0 (global index of local plane 0), ck0, ck1 (coarse planes it

@@ -324,6 +324,11 @@ def dist_init(rank, nranks, uid, lib=None):
     _check(L.ndsm_hip_dist_init(int(rank), int(nranks), ctypes.c_char_p(uid)), "ndsm_hip_dist_init", L)
 
 
+def dist_finalize(lib=None):
+    L = lib or load_library()
+    _check(L.ndsm_hip_dist_finalize(), "ndsm_hip_dist_finalize", L)
+
+
 def poisson_solve(u, rhs, mesh, bcs, ms=5, ex_tol=1e-13, du_max=True, nmax_exact=10000, vc_tol=1e-10, nmax=1024,
                   ngrids=0, hist_len=0, lib=None, precision=0):
     """laplace(u) = rhs on the device.  u: initial guess + Dirichlet data,

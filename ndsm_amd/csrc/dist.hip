@@ -68,7 +68,7 @@ int ndsmk_dist_init(int rank, int nranks, const void *id128) {
 
 int ndsmk_dist_finalize(void) {
   if (!g_d.up) return 0;
-  (void)hipStreamSynchronize(ndsm::stream());
+  (void)ndsmk_sync();
   ncclCommDestroy(g_d.comm);
   (void)hipFree(g_d.d_red);
   g_d = Dist();

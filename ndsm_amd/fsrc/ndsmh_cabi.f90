@@ -36,6 +36,10 @@ module ndsmh_cabi
       type(c_ptr), value :: id128
       integer(c_int) :: rc
     end function
+    function ndsmk_dist_finalize() bind(c, name="ndsmk_dist_finalize") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
   end interface
 
   interface
@@ -510,6 +514,12 @@ contains
     type(c_ptr), value :: id128
     integer(c_int) :: rc
     rc = ndsmk_dist_init(rank, nranks, id128)
+  end function
+
+  ! drains the library streams and destroys the communicator (collective: every rank calls it)
+  function ndsm_hip_dist_finalize() bind(c, name="ndsm_hip_dist_finalize") result(rc)
+    integer(c_int) :: rc
+    rc = ndsmk_dist_finalize()
   end function
 
   ! The slab plan every rank derives (pure host arithmetic, no GPU needed).

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, ndsm_amd
 from ndsm_amd import _lib
 L = ndsm_amd.load_library(); assert L.ndsm_hip_init(0) == 0
-for n in (128, 160, 192):
+for n in [int(a) for a in sys.argv[1:]] or (128, 160, 192):
     mesh = [np.linspace(0, 1, n)] * 3
     S = _lib.MGSolver([n, n, n], mesh, "NDDNDD")
     rng = np.random.default_rng(1)

@@ -1,0 +1,111 @@
+"""Multi-process rehearsal of the z-slab path on ONE GPU.
+
+RCCL refuses two ranks on one device, and the driver's 2/4/8-GPU runs are the only place the
+per-rank code path (World(rank=r) + dist.hip) would otherwise execute.  Here N processes share the
+box's GPU with tests/fake_rccl (a strict shared-memory stand-in for the nine RCCL calls the library
+makes - TEST DOUBLE, see its header) linked under the product's own objects (libndsm_hip_fake.so): ordering, peer bookkeeping, message sizes and
+deadlock-freedom of the real product code are exercised, and every rank's planes must equal the
+single-domain solver's bit for bit.  What it cannot cover: RCCL/xGMI themselves."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_rccl", "libndsm_hip_fake.so")
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ndsm_amd
+    from ndsm_amd import _lib
+    L = ndsm_amd.load_library()
+    assert L.ndsm_hip_init(0) == 0, _lib.last_error(L)
+    return _lib
+
+
+def _fake():
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])     # no-op when up to date
+    return FAKE
+
+
+def _run_world(tmp_path, world, cases, timeout=300):
+    out = str(tmp_path)
+    json.dump(cases, open(os.path.join(out, "cases.json"), "w"))
+    env = dict(os.environ, NDSM_HIP_LIB=_fake(), FAKE_RCCL_TIMEOUT="60")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), str(r), str(world), out],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs, codes = [], []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=timeout)
+            logs.append(o)
+            codes.append(p.returncode)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(c == 0 for c in codes), "\n".join(f"--- rank {i} rc {c}\n{l[-3000:]}" for i, (c, l) in enumerate(zip(codes, logs)))
+    return out
+
+
+def _check_against_single(hip, out, world, cases):
+    from golden_inputs import rand_field, uniform_mesh
+    for ci, c in enumerate(cases):
+        ns = c["ns"]
+        mesh = uniform_mesh(ns)
+        shp = tuple(ns[::-1])
+        u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
+        S = hip.MGSolver(ns, mesh, c["bcs"])
+        infos = [json.load(open(os.path.join(out, f"c{ci}_r{r}.json"))) for r in range(world)]
+        assert infos[0]["z0"] == 0 and infos[-1]["z1"] == ns[2]
+        assert all(infos[r]["z1"] == infos[r + 1]["z0"] for r in range(world - 1))
+        if "levels" in c:
+            assert all(i["dist_levels"] == c["levels"] for i in infos), [i["dist_levels"] for i in infos]
+
+        def gathered(tag):
+            return np.concatenate([np.load(os.path.join(out, f"c{ci}_{tag}_r{r}.npy")) for r in range(world)], axis=0)
+
+        def fresh():
+            S.upload(1, hip.BUF_U, u)
+            if c.get("laplace"):
+                S.zero_rhs()
+            else:
+                S.upload(1, hip.BUF_RHS, rhs)
+
+        fresh()
+        S.op(hip.OP_RELAX, 1, 3)
+        assert np.array_equal(gathered("relax"), S.download(1, hip.BUF_U)), f"case {ci} sweeps"
+        fresh()
+        S.vcycle(2)
+        assert np.array_equal(gathered("vcycle"), S.download(1, hip.BUF_U)), f"case {ci} vcycle"
+        ierr, du, nc, hist = S.solve(hist_len=64)
+        for i in infos:      # every rank sees the same all-reduced history and stops in the same cycle
+            assert (i["ierr"], i["nc"]) == (ierr, nc) and i["hist"] == [float(h) for h in hist], (ci, i["nc"], nc)
+        assert np.array_equal(gathered("solve"), S.download(1, hip.BUF_U)), f"case {ci} solve"
+        S.close()
+
+
+@pytest.mark.parametrize("world", (2, 3))
+def test_ranks_on_one_gpu_bitwise(hip, tmp_path, world):
+    """level 1 in slabs, levels >= 2 on rank 0; with and without the overlapped halo exchange"""
+    cases = [
+        {"ns": [64, 48, 96], "bcs": "NDDNDD"},
+        {"ns": [64, 48, 96], "bcs": "DDNDDN", "env": {"NDSM_HIP_OVERLAP": "0"}},
+        {"ns": [66, 40, 72], "bcs": "DNDDND", "laplace": True},
+    ]
+    out = _run_world(tmp_path, world, cases)
+    _check_against_single(hip, out, world, cases)
+
+
+@pytest.mark.parametrize("world,ns,levels", ((4, [64, 64, 256], 2), (2, [128, 64, 256], 3)), ids=str)
+def test_ranks_on_one_gpu_distributed_levels(hip, tmp_path, world, ns, levels):
+    """several distributed levels: child worlds, restriction into the own slab of the next level"""
+    cases = [{"ns": ns, "bcs": b, "levels": levels, "env": {"NDSM_HIP_DIST_LEVELS": str(levels)}} for b in ("NDDNDD", "DDNDDN")]
+    out = _run_world(tmp_path, world, cases)
+    _check_against_single(hip, out, world, cases)
