@@ -356,9 +356,18 @@ def main():
         except Exception:
             traffic = None
 
-    if rank != 0:
+    def finish():
+        # after the result line is out: leave together, then take the communicator down (collective)
         if dist is not None:
             dist.barrier()
+            if rccl_ok:
+                try:
+                    _lib.dist_finalize(L)
+                except Exception as exc:  # noqa: BLE001
+                    print(f"bench: dist_finalize: {exc}", file=sys.stderr, flush=True)
+
+    if rank != 0:
+        finish()
         return
     out = {
         "metric": "fine-grid LUP/s (RB-GS smoother updates per second of V-cycle time, fp64)",
@@ -395,8 +404,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
+    finish()
 
 
 if __name__ == "__main__":

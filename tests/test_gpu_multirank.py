@@ -109,3 +109,20 @@ def test_ranks_on_one_gpu_distributed_levels(hip, tmp_path, world, ns, levels):
     cases = [{"ns": ns, "bcs": b, "levels": levels, "env": {"NDSM_HIP_DIST_LEVELS": str(levels)}} for b in ("NDDNDD", "DDNDDN")]
     out = _run_world(tmp_path, world, cases)
     _check_against_single(hip, out, world, cases)
+
+
+def test_bench_two_ranks_rehearsal(hip):
+    """the driver's N=2 command line (torch.distributed.run, gloo rendezvous, slab world, self-check,
+    ONE JSON line from rank 0), both ranks on this box's GPU over the test double"""
+    env = dict(os.environ, NDSM_HIP_LIB=_fake(), FAKE_RCCL_TIMEOUT="120", FAKE_RCCL_SLOT_MB="64")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert "z-slabs" in out["config"]["parallelism"], out["config"]
+    assert out["slab_check"].startswith("bit-identical"), out["slab_check"]
+    assert "fake_rccl" in out["rocm_stack"]["rccl"]
