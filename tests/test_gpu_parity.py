@@ -821,6 +821,41 @@ def test_full_size_config4_loopback(hip):
 
 
 @pytest.mark.gpu
+def test_beyond_int32_points_loopback(hip):
+    """2048 x 2048 x 520 = 2.18e9 points (> 2^31; 16 GiB per array - BASELINE config[4]'s plane size,
+    half its depth; scripts/check_c5_size.py runs the full 2^32-point grid the same way): one V-cycle of
+    the single-domain solver, whose linear indices leave 32-bit range, against the loop-back world of 8
+    z-slabs, whose do not - bit for bit.  Needs ~50 GiB of host memory and ~100 GB of HBM."""
+    with open("/proc/meminfo") as f:
+        avail = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 2**20
+    if avail < 80:
+        pytest.skip(f"only {avail:.0f} GiB of host memory available")
+    ns = [2048, 2048, 520]
+    dx = 1.0 / (ns[0] - 1)
+    mesh = [np.arange(n) * dx for n in ns]
+    rng = np.random.default_rng(12)
+    plane = rng.uniform(-1, 1, (ns[1], ns[0]))
+    zf = np.cos(np.arange(ns[2]) * 0.37) + 0.01 * np.arange(ns[2])
+    u = np.empty((ns[2], ns[1], ns[0]))
+    for k in range(ns[2]):
+        np.multiply(plane, zf[k], out=u[k])
+        u[k, (k * 7) % ns[1]] += 0.5
+    S = hip.MGSolver(ns, mesh, "DNDDND")
+    S.upload(1, hip.BUF_U, u)
+    S.zero_rhs()
+    S.vcycle(1)
+    a = S.download(1, hip.BUF_U)
+    S.close()
+    W = hip.World(ns, mesh, "DNDDND", 8)
+    W.upload(hip.BUF_U, u)
+    W.zero_rhs()
+    W.vcycle(1)
+    b = W.download(hip.BUF_U)
+    W.close()
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_baseline_config0_three_level_cycle(hip, port):
     """BASELINE config[0]: 64^3 Poisson, 3-level V-cycle (additive option slot get_iopt_ngrids; the
     coarsest grid is then 16^3 = 4096 points, beyond the single-workgroup coarse kernel, so the
