@@ -72,6 +72,7 @@ __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const TF *__restrict
   const int ck = t2 / a.nti;
 
   const int nx = a.nf[0], ny = a.nf[1];
+  const bool oddx = (nx & 1) != 0;
   const size_t sz = (size_t)nx * (size_t)ny;
   const int I0 = ti * CI, J0 = tj * CJ;
   // coarse planes of this chunk, GLOBAL numbering (the z tables are global)
@@ -122,7 +123,17 @@ __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const TF *__restrict
       d2 t_;                                                                             \
       t_.x = 0.0;                                                                        \
       t_.y = 0.0;                                                                        \
-      if (p_ < NPAIR && i_ + 1 < nx && j_ < ny && (kglob) <= kB) t_ = ld2(f + sz * (size_t)kl_ + (i_ + nx * j_)); \
+      if (p_ < NPAIR && i_ < nx && j_ < ny && (kglob) <= kB) {                           \
+        const TF *q_ = f + sz * (size_t)kl_ + (i_ + nx * j_);                            \
+        if (!oddx) {                                                                     \
+          t_ = ld2(q_);                                                                  \
+        } else { /* odd nx: rows are not 16-byte aligned and the last pair is half outside */ \
+          const TF *q1_ = q_ + 1;                                                        \
+          asm volatile("" : "+v"(q1_));                                                  \
+          t_.x = q_[0];                                                                  \
+          if (i_ + 1 < nx) t_.y = q1_[0];                                                \
+        }                                                                                \
+      }                                                                                  \
       dst[s_] = t_;                                                                      \
     }                                                                                    \
   } while (0)

@@ -10,7 +10,8 @@
 // used here (per workgroup; the comment on rbgs3_fused_k has the pipeline in detail):
 //
 //   * an (x,y) tile of TXH x TYH points, of which the inner TXI x TYI are owned (written back) and
-//     a ring as deep as the pipeline is halo, updated redundantly as far as it stays valid;
+//     a ring as deep as the pipeline is halo, updated redundantly as far as it stays valid (a halo
+//     that reaches the physical face stays valid throughout and is owned as well);
 //   * the tile is streamed through a z chunk [zs, ze) as a 2S-stage pipeline skewed along z:
 //     iteration k runs stage t (even red, odd black) on plane k - t.  The z+1 neighbour comes
 //     from the register the previous stage just produced, everything else from LDS planes kept
@@ -31,8 +32,18 @@
 // correction added to every plane as it is loaded.  T = double is the reference's arithmetic;
 // T = float serves the correction equation of the mixed-precision mode.
 //
-// Requirements of this path (otherwise smooth.hip runs): 3-D, nx even, >= 16 x 16 points per
-// plane; z-slabs enter through k0 / nzg / zown0 / zown1 of the grid descriptor.
+// Requirements of this path (otherwise smooth.hip runs): 3-D, >= 16 x 16 points per plane;
+// z-slabs enter through k0 / nzg / zown0 / zown1 of the grid descriptor.
+//
+// Odd nx (template parameter ODD; 2^k + 1 grids, and every other level of NDSM's floor-halving
+// hierarchy): the pair grid still starts at an even index, so the last column nx-1 is element 0 of
+// a pair whose element 1 lies outside the row.  That element is kept as a GHOST that mirrors
+// column nx-2: it is loaded from there, carries that column's flags, stage budget and right-hand
+// side, and takes column nx-3 as its outer neighbour - so it receives the same update, from the
+// same operands, in the same stage ((a + b) commutes) and stays equal to u(nx-2) bit for bit.
+// Column nx-1 thus finds its Neumann mirror value where any interior point finds its x+1
+// neighbour, and the inner loop is unchanged; only loads (rows are 8-byte aligned now), stores
+// (the ghost is never written back) and the per-slot constants differ.
 #include "common.hpp"
 
 #include <cstdlib>
@@ -87,6 +98,30 @@ __device__ __forceinline__ void st2(T *p, const P2<T> &a) {
   t.y = a.y;
   *reinterpret_cast<typename Vec2<T>::type *>(p) = t;
 }
+// rows of an odd-nx level start at odd multiples of sizeof(T): same 16-byte (8-byte) access, but the
+// compiler must not assume natural alignment
+template <typename T>
+__device__ __forceinline__ P2<T> ld2u(const T *p) {
+  typedef T vec2 __attribute__((ext_vector_type(2)));
+  typedef vec2 vec2u __attribute__((aligned(sizeof(T))));
+  (void)sizeof(vec2u);
+  const T *p1 = p + 1;
+  asm volatile("" : "+v"(p1));   // two element-sized accesses: a straddling 16-byte one costs more
+  P2<T> r;
+  r.x = *p;
+  r.y = *p1;
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void st2u(T *p, const P2<T> &a) {
+  typedef T vec2 __attribute__((ext_vector_type(2)));
+  typedef vec2 vec2u __attribute__((aligned(sizeof(T))));
+  (void)sizeof(vec2u);
+  T *p1 = p + 1;
+  asm volatile("" : "+v"(p1));
+  *p = a.x;
+  *p1 = a.y;
+}
 // by value: selects on values, never on addresses
 template <typename T>
 __device__ __forceinline__ T pick(const P2<T> a, int e) {
@@ -98,7 +133,7 @@ __device__ __forceinline__ T pick(const P2<T> a, int e) {
 template <int TXH, int TYH, int NT, int HX, int HY>
 struct Slot {
   int li, lj, i, j, lo;
-  bool live, in, own;
+  bool live, in;
   __device__ __forceinline__ Slot(int tid, int s, int x0, int y0, int nx, int ny) {
     constexpr int NPX = TXH / 2;
     const int p = tid + NT * s;
@@ -108,7 +143,6 @@ struct Slot {
     j = y0 + lj;
     live = p < NPX * TYH;
     in = live && i >= 0 && i + 1 < nx && j >= 0 && j < ny;
-    own = in && li >= HX && li < TXH - HX && lj >= HY && lj < TYH - HY;
     lo = live ? p : 0;  // pair number = index inside each half of an LDS plane
   }
 };
@@ -158,7 +192,7 @@ struct Slot {
 // LVL1 changes nothing but the kernel's name: launches on levels of >= 64 M points get a symbol of
 // their own, so that a rocprofv3 --stats summary does not average the level-1 launches (the
 // ones bench.py's roofline line is quoted on) with the much shorter ones of the coarser levels.
-template <typename T, int S, int TXH, int TYH, int NT, int WPS, bool RHS0, int MODE, bool LVL1>
+template <typename T, int S, int TXH, int TYH, int NT, int WPS, bool RHS0, int MODE, bool LVL1, bool ODD>
 __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u, T *__restrict__ uout,
                                                          const T *__restrict__ rhs, T *__restrict__ rout,
                                                          const T *__restrict__ prev, double *__restrict__ part,
@@ -199,6 +233,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   const int cz = t2 / pl.ntx;
 
   const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
+  const int nxs = ODD ? nx + 1 : nx;  // row length in whole pairs (ODD: the last pair's element 1 is the ghost)
   const int x0 = tx * TXI - HX, y0 = ty * TYI - NSTG;
   const int zs = g.zown0 + cz * pl.zc;
   const int ze = min(zs + pl.zc, g.zown1);
@@ -210,16 +245,41 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   const int fp = g.first_par & 1;
   // tile edges that coincide with the physical boundary do not shrink the valid region
   const bool openxl = x0 > 0, openxh = x0 + TXH < nx, openyl = y0 > 0, openyh = y0 + TYH < ny;
+  // pair at offset go_ of a global plane: plain 16-byte access, or (ODD) an unaligned one and, for the
+  // pair that holds column nx-1 (flag bit 4), that column plus the ghost's source / nothing
+  auto ldpair = [&](const T *p, int fl_) {
+    if (ODD) {
+      d2 r;
+      if (fl_ & 16) {
+        r.x = p[0];
+        r.y = p[-1];
+      } else {
+        r = ld2u(p);
+      }
+      return r;
+    }
+    return ld2(p);
+  };
+  auto stpair = [&](T *p, const d2 &v, int fl_) {
+    if (ODD) {
+      if (fl_ & 16)
+        p[0] = v.x;
+      else
+        st2u(p, v);
+    } else {
+      st2(p, v);
+    }
+  };
 
 #define NDSM_LOAD_PLANE(base, k, dst)                              \
   do {                                                              \
     const T *pk_ = (base) + sz * (size_t)(k);                  \
     _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {             \
-      const SlotT q_(tid, s_, x0, y0, nx, ny);                      \
+      const SlotT q_(tid, s_, x0, y0, nxs, ny);                     \
       d2 t_;                                                        \
       t_.x = 0.0;                                                   \
       t_.y = 0.0;                                                   \
-      if (q_.in) t_ = ld2(pk_ + (q_.i + nx * q_.j));                \
+      if (q_.in) t_ = ldpair(pk_ + (q_.i + nx * q_.j), (ODD && q_.i == nx - 1) ? 16 : 0); \
       dst[s_] = t_;                                                 \
     }                                                               \
   } while (0)
@@ -263,11 +323,12 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     int xlo, xhi;  // outer x neighbour of element 0 / 1 (the pair partner where mirrored; always a
                    // valid offset, never-updated elements point at themselves)
     int go;        // offset of the pair inside a global plane
-    int fl;        // bit 0 in-domain, 1 owned, 2/3 element 0/1 inside the x-y update bounds, 6 parity
+    int fl;        // bit 0 in-domain, 1 owned, 2/3 element 0/1 inside the x-y update bounds, 4 (ODD) the pair
+                   // of column nx-1 whose element 1 is the ghost, 6 parity
                    // base, bits 8-11 / 12-15: how many stages element 0 / 1 may take (0: never updated)
   };
   auto make_sc = [&](int tid_, int s) {
-    const SlotT q(tid_, s, x0, y0, nx, ny);
+    const SlotT q(tid_, s, x0, y0, nxs, ny);
     SC c;
     c.lo = SZ * q.lo;
     c.go = q.i + nx * q.j;
@@ -277,20 +338,28 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     c.yh = !yok ? 0 : ((q.j == ny - 1) ? -SZ * NPX : SZ * NPX);
     const bool yin = q.j >= g.lb[1] && q.j <= g.ub[1];
     const bool in0 = yin && q.i >= g.lb[0] && q.i <= g.ub[0];
-    const bool in1 = yin && q.i + 1 >= g.lb[0] && q.i + 1 <= g.ub[0];
+    const bool ghost = ODD && q.in && q.i == nx - 1;   // element 1 mirrors column nx-2 (header)
+    const int i1 = ghost ? q.i - 1 : q.i + 1;           // the column element 1 stands for
+    const bool in1 = yin && i1 >= g.lb[0] && i1 <= g.ub[0];
     const bool mir0 = q.i == 0, mir1 = q.i + 1 == nx - 1;
     const int ry = min(openyl ? q.lj : BIG, openyh ? TYH - 1 - q.lj : BIG);
     int r0 = min(min(openxl ? q.li : BIG, openxh ? TXH - 1 - q.li : BIG), ry);
     int r1 = min(min(openxl ? q.li + 1 : BIG, openxh ? TXH - 2 - q.li : BIG), ry);
+    if (ghost) r1 = min(openxl ? q.li - 1 : BIG, ry);   // column nx-2's budget (this tile ends at the face)
     // the outer x neighbour must be in the tile unless it is mirrored
     if (!mir0 && q.li - 1 < 0) r0 = 0;
-    if (!mir1 && q.li + 2 >= TXH) r1 = 0;
+    if (!mir1 && !ghost && q.li + 2 >= TXH) r1 = 0;
     if (!yok || !q.in) r0 = r1 = 0;
     if (!in0) r0 = 0;
     if (!in1) r1 = 0;
     c.xlo = mir0 ? c.lo + HALF : (q.li - 1 >= 0 ? c.lo + HALF - SZ : c.lo);
     c.xhi = mir1 ? c.lo : (q.li + 2 < TXH ? c.lo + SZ : c.lo + HALF);
-    int fl = (q.in ? 1 : 0) | (q.own ? 2 : 0) | (in0 ? 4 : 0) | (in1 ? 8 : 0);
+    if (ghost) c.xhi = c.lo - SZ;                       // column nx-3: element 0 of the previous pair (li >= HX >= 2)
+    // owned = written back by this workgroup: the inner TXI x TYI points, and - in the last tile of a
+    // row / column of tiles, whose halo reaches the physical face (launch_cfg counts tiles that way) -
+    // the halo points up to that face too: they stay valid through every stage, nothing shrinks there
+    const bool own = q.in && q.li >= HX && q.lj >= NSTG && (q.li < TXH - HX || !openxh) && (q.lj < TYH - NSTG || !openyh);
+    int fl = (q.in ? 1 : 0) | (own ? 2 : 0) | (in0 ? 4 : 0) | (in1 ? 8 : 0) | (ghost ? 16 : 0);
     fl |= ((q.i + q.j + g.k0 + fp) & 1) ? 64 : 0;
     fl |= min(r0, 15) << 8;
     fl |= min(r1, 15) << 12;
@@ -323,7 +392,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     cy0 = pa.plo[1][ja];
 #pragma unroll
     for (int s = 0; s < (PROL ? NS : 1); ++s) {
-      const SlotT q(tid, s, x0, y0, nx, ny);
+      const SlotT q(tid, s, x0, y0, nxs, ny);
       p_jl[s] = 0;
       p_wly[s] = p_why[s] = 0.0;
 #pragma unroll
@@ -337,9 +406,10 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
         p_why[s] = pa.pwh[1][q.j];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          p_il[s][h] = pa.plo[0][q.i + h] - cx0;
-          p_wlx[s][h] = pa.pwl[0][q.i + h];
-          p_whx[s][h] = pa.pwh[0][q.i + h];
+          const int ih = (ODD && q.i + h >= nx) ? q.i - 1 : q.i + h;   // the ghost gets column nx-2's correction
+          p_il[s][h] = pa.plo[0][ih] - cx0;
+          p_wlx[s][h] = pa.pwl[0][ih];
+          p_whx[s][h] = pa.pwh[0][ih];
         }
       }
     }
@@ -440,7 +510,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     T *B0 = lds + (ks % NSTG) * PLANE;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const SlotT q(tid, s, x0, y0, nx, ny);
+      const SlotT q(tid, s, x0, y0, nxs, ny);
       if (q.live) {
         B0[q.lo] = c0[s].x;
         B0[NPAIR + q.lo] = c0[s].y;
@@ -475,13 +545,13 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       const T *pk = u + sz * (size_t)(k + 2);
 #pragma unroll
       for (int s = 0; s < NS; ++s)
-        if (scs[s].fl & 1) nn[s] = ld2(pk + scs[s].go);
+        if (scs[s].fl & 1) nn[s] = ldpair(pk + scs[s].go, scs[s].fl);
     }
     if (!RHS0 && k + 1 <= ke) {
       const T *pk = rhs + sz * (size_t)(k + 1);
 #pragma unroll
       for (int s = 0; s < (RHS0 ? 1 : NS); ++s)
-        if (scs[s].fl & 1) rn[s] = ld2(pk + scs[s].go);
+        if (scs[s].fl & 1) rn[s] = ldpair(pk + scs[s].go, scs[s].fl);
     }
 
 
@@ -492,7 +562,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 #pragma unroll
       for (int s = 0; s < (MET ? NS : 1); ++s) {
         pvh[s].x = pvh[s].y = 0.0;
-        if (pf >= zs && pf < ze && (scs[s].fl & 2)) pvh[s] = ld2(prev + sz * (size_t)pf + scs[s].go);
+        if (pf >= zs && pf < ze && (scs[s].fl & 2)) pvh[s] = ldpair(prev + sz * (size_t)pf + scs[s].go, scs[s].fl);
       }
     }
 
@@ -573,7 +643,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
         fin.x = LDSD(bufoff(NST - 1) + c.lo);
         fin.y = LDSD(bufoff(NST - 1) + c.lo + HALF);
         fin_st[s] = pf >= zs && pf < ze && (fl & 2);
-        if (!DEFER && fin_st[s]) st2(uout + sz * (size_t)pf + c.go, fin);
+        if (!DEFER && fin_st[s]) stpair(uout + sz * (size_t)pf + c.go, fin, fl);
         if (!RES) mLe[RES ? 0 : s] = pick(fin, 1 - ee[s]);
       }
       finh[s] = fin;
@@ -607,7 +677,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
           if (DEFER)
             resh[RES ? s : 0] = res;
           else
-            st2(rout + sz * (size_t)pr + c.go, res);
+            stpair(rout + sz * (size_t)pr + c.go, res, fl);
         }
         f2[RES ? s : 0] = cc;
         f1[RES ? s : 0] = fin;
@@ -647,13 +717,13 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     for (int s = 0; s < (DEFER ? NS : 0); ++s) {
       if (MET && fin_st[s]) {
         const double d0 = fabs((double)finh[s].x - (double)pvh[MET ? s : 0].x);
-        const double d1 = fabs((double)finh[s].y - (double)pvh[MET ? s : 0].y);
+        const double d1 = (ODD && (scs[s].fl & 16)) ? 0.0 : fabs((double)finh[s].y - (double)pvh[MET ? s : 0].y);
         met_mx = fmax(met_mx, fmax(d0, d1));
         met_sm = met_sm + d0;
         met_sm = met_sm + d1;
       }
-      if (fin_st[s]) st2(uout + sz * (size_t)(k - (NST - 1)) + scs[s].go, finh[s]);
-      if (RES && res_st[RES ? s : 0]) st2(rout + sz * (size_t)(k - NST) + scs[s].go, resh[RES ? s : 0]);
+      if (fin_st[s]) stpair(uout + sz * (size_t)(k - (NST - 1)) + scs[s].go, finh[s], scs[s].fl);
+      if (RES && res_st[RES ? s : 0]) stpair(rout + sz * (size_t)(k - NST) + scs[s].go, resh[RES ? s : 0], scs[s].fl);
     }
     kb = (kb + 1 == NSTG) ? 0 : kb + 1;
     __syncthreads();
@@ -726,7 +796,7 @@ int met_scratch(size_t nblk, double **part, double **out2) {
   return 0;
 }
 
-template <typename T, int S, int TXH, int TYH, int NT, int WPS, int MODE = 0, bool LVL1 = false>
+template <typename T, int S, int TXH, int TYH, int NT, int WPS, int MODE = 0, bool LVL1 = false, bool ODD = false>
 int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int target_wgs, T *rout = nullptr,
                const T *prev = nullptr, const ProlArgs *prol = nullptr) {
   constexpr bool RES = MODE == 1;
@@ -734,24 +804,27 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
   constexpr int TXI = TXH - 2 * ((NST + 1) & ~1), TYI = TYH - 2 * NST;
   static_assert(TXI > 0 && TYI > 0 && (TXH % 2) == 0, "tile");
   FusedPlan pl;
-  pl.ntx = (g.n[0] + TXI - 1) / TXI;
-  pl.nty = (g.n[1] + TYI - 1) / TYI;
+  // the last tile also owns the part of its halo that lies inside the domain (make_sc): n tiles
+  // reach n * TXI + halo points
+  constexpr int HXL = (NST + 1) & ~1;
+  pl.ntx = g.n[0] > HXL ? (g.n[0] - HXL + TXI - 1) / TXI : 1;
+  pl.nty = g.n[1] > NST ? (g.n[1] - NST + TYI - 1) / TYI : 1;
   const int tiles = pl.ntx * pl.nty;
   const int nzo = g.zown1 - g.zown0;  // owned planes
   const size_t lds_bytes = sizeof(T) * NST * TXH * TYH + (MODE == 3 ? 2 * sizeof(double) * (TXH / 2 + 3) * (TYH / 2 + 3) : 0);
   static bool attr_set[2] = {false, false};
   static int wgs_per_cu[2] = {1, 1};
   const int v = rhs ? 0 : 1;
-  const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1>)
-                         : reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1>);
+  const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1, ODD>)
+                         : reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1, ODD>);
   if (!attr_set[v]) {
     NDSM_HIP(hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int occ = 1;
     if (rhs)
-      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1>, NT,
+      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1, ODD>, NT,
                                                             lds_bytes));
     else
-      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1>, NT,
+      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1, ODD>, NT,
                                                             lds_bytes));
     wgs_per_cu[v] = occ > 0 ? occ : 1;
     attr_set[v] = true;
@@ -792,12 +865,12 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
     if (int rc = met_scratch((size_t)nblk, &part, &out2)) return rc;
   }
   if (rhs)
-    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1>), dim3(nblk), dim3(NT), lds_bytes,
+    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1, ODD>), dim3(nblk), dim3(NT), lds_bytes,
                        ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl, pa);
   else  // the level's rhs is identically zero (level 1 of NDSM's Laplace problems,
         // ndsm_vector_potential.f90:640-641): x - 0.0 == x exactly, so the variant that never
         // loads rhs returns the same bits with 8 B/LUP less traffic
-    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1>), dim3(nblk), dim3(NT), lds_bytes,
+    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1, ODD>), dim3(nblk), dim3(NT), lds_bytes,
                        ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl, pa);
   NDSM_LAUNCH_CHECK();
   if (MODE == 2) {
@@ -830,14 +903,14 @@ static const int *fused_cfg() {
 // rout != nullptr: the caller wants the residual of the swept field as well.  It is
 // produced (and *res_done set) only by the launch that performs the LAST of the
 // max_sweeps sweeps, i.e. when this call runs a single sweep with max_sweeps == 1.
-template <typename T>
+template <typename T, bool ODD = false>
 static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int max_sweeps, bool force,
                           int *sweeps_done, T *rout, int *res_done, const T *prev = nullptr, int *met_done = nullptr,
                           const ProlArgs *prol = nullptr) {
   *sweeps_done = 0;
   if (res_done) *res_done = 0;
   if (met_done) *met_done = 0;
-  if (!uout || g.ndim != 3 || (g.n[0] & 1) || g.n[0] < 16 || g.n[1] < 16 || g.zown1 - g.zown0 < (force ? 1 : 8))
+  if (!uout || g.ndim != 3 || ((g.n[0] & 1) != 0) != ODD || g.n[0] < 16 || g.n[1] < 16 || g.zown1 - g.zown0 < (force ? 1 : 8))
     return 0;
   // a z-streaming workgroup walks >= 16 planes serially: with fewer than ~one
   // workgroup per CU the sweep is latency bound and the two colour passes win
@@ -866,7 +939,7 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   if (prol) {
     if constexpr (std::is_same<T, double>::value) {
       if (!rhs && two && !slab && !(met && max_sweeps == 2) && cfg[0] == 0) {
-        rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 3>(g, u, uout, rhs, tgt, nullptr, nullptr, prol));
+        rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 3, false, ODD>(g, u, uout, rhs, tgt, nullptr, nullptr, prol));
         if (rc) return rc;
         *sweeps_done = 2;
       }
@@ -875,7 +948,7 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   }
   if constexpr (std::is_same<T, double>::value) {
     if (met && two && max_sweeps == 2) {
-      rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 2>(g, u, uout, rhs, tgt, nullptr, prev));
+      rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 2, false, ODD>(g, u, uout, rhs, tgt, nullptr, prev));
       if (rc) return rc;
       *sweeps_done = 2;
       *met_done = 1;
@@ -883,9 +956,9 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
     }
     if (met && !two && max_sweeps == 1 && !res) {
       if (big)
-        rc = (launch_cfg<T, 1, 132, 31, 1024, 4, 2>(g, u, uout, rhs, tgt, nullptr, prev));
+        rc = (launch_cfg<T, 1, 132, 31, 1024, 4, 2, false, ODD>(g, u, uout, rhs, tgt, nullptr, prev));
       else
-        rc = (launch_cfg<T, 1, 132, 23, 768, 4, 2>(g, u, uout, rhs, tgt, nullptr, prev));
+        rc = (launch_cfg<T, 1, 132, 23, 768, 4, 2, false, ODD>(g, u, uout, rhs, tgt, nullptr, prev));
       if (rc) return rc;
       *sweeps_done = 1;
       *met_done = 1;
@@ -893,22 +966,30 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
     }
   }
   if (two) {
-    switch (cfg[0]) {
-      case 3: rc = launch_cfg<T, 2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;
-      case 5: rc = launch_cfg<T, 2, 72, 28, 512, 4>(g, u, uout, rhs, tgt); break;
-      default:
-        rc = big ? (launch_cfg<T, 2, 136, 30, 1024, 4, 0, true>(g, u, uout, rhs, tgt))
-                 : (launch_cfg<T, 2, 136, 30, 1024, 4>(g, u, uout, rhs, tgt));
-        break;
+    if constexpr (ODD) {   // the tuning alternates and the level-1 symbol exist for even nx only
+      rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 0, false, true>(g, u, uout, rhs, tgt));
+    } else {
+      switch (cfg[0]) {
+        case 3: rc = launch_cfg<T, 2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;
+        case 5: rc = launch_cfg<T, 2, 72, 28, 512, 4>(g, u, uout, rhs, tgt); break;
+        default:
+          rc = big ? (launch_cfg<T, 2, 136, 30, 1024, 4, 0, true>(g, u, uout, rhs, tgt))
+                   : (launch_cfg<T, 2, 136, 30, 1024, 4>(g, u, uout, rhs, tgt));
+          break;
+      }
     }
     if (rc) return rc;
     *sweeps_done = 2;
     return 0;
   }
   if (res && max_sweeps == 1) {
-    switch (cfg[2]) {
-      case 1: rc = (launch_cfg<T, 1, 136, 30, 1024, 4, 1>(g, u, uout, rhs, tgt, rout)); break;
-      default: rc = (launch_cfg<T, 1, 136, 22, 768, 4, 1>(g, u, uout, rhs, tgt, rout)); break;
+    if constexpr (ODD) {
+      rc = (launch_cfg<T, 1, 136, 22, 768, 4, 1, false, true>(g, u, uout, rhs, tgt, rout));
+    } else {
+      switch (cfg[2]) {
+        case 1: rc = (launch_cfg<T, 1, 136, 30, 1024, 4, 1>(g, u, uout, rhs, tgt, rout)); break;
+        default: rc = (launch_cfg<T, 1, 136, 22, 768, 4, 1>(g, u, uout, rhs, tgt, rout)); break;
+      }
     }
     if (rc) return rc;
     *sweeps_done = 1;
@@ -916,8 +997,8 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
     return 0;
   }
   switch (cfg[1] ? cfg[1] : (big ? 7 : 8)) {
-    case 8: rc = launch_cfg<T, 1, 132, 23, 768, 4>(g, u, uout, rhs, tgt); break;
-    default: rc = launch_cfg<T, 1, 132, 31, 1024, 4>(g, u, uout, rhs, tgt); break;
+    case 8: rc = (launch_cfg<T, 1, 132, 23, 768, 4, 0, false, ODD>(g, u, uout, rhs, tgt)); break;
+    default: rc = (launch_cfg<T, 1, 132, 31, 1024, 4, 0, false, ODD>(g, u, uout, rhs, tgt)); break;
   }
   if (rc) return rc;
   *sweeps_done = 1;
@@ -942,8 +1023,12 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
       *sweeps_done = 0;  // windows (z-slabs) are not built into this mode
       return 0;
     }
+    if (g.n[0] & 1)
+      return launch_fused_t<double, true>(g, u, uout, rhs, max_sweeps, force, sweeps_done, rout, res_done, prev, met_done, &pa);
     return launch_fused_t<double>(g, u, uout, rhs, max_sweeps, force, sweeps_done, rout, res_done, prev, met_done, &pa);
   }
+  if (g.n[0] & 1)
+    return launch_fused_t<double, true>(g, u, uout, rhs, max_sweeps, force, sweeps_done, rout, res_done, prev, met_done);
   return launch_fused_t<double>(g, u, uout, rhs, max_sweeps, force, sweeps_done, rout, res_done, prev, met_done);
 }
 

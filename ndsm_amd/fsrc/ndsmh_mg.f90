@@ -258,10 +258,11 @@ contains
     type(axis_xfer_t), intent(in) :: t(3)
     integer(c_int) :: ok
     integer(c_int) :: ci, cj, fx, fy, mt
-    integer :: a0, a1, f0, nt, k
+    integer :: a0, a1, f0, nt, k, st
     ok = 0
     if (s%ndim /= 3) return
-    if (mod(s%lev(l)%n(1), 2) /= 0) return
+    call get_environment_variable("NDSM_HIP_NO_STREAM_RESTRICT", status=st)   ! development switch
+    if (st == 0) return
     call ndsmk_restrict_stream_tile(ci, cj, fx, fy, mt)
     if (any([t(1)%maxt, t(2)%maxt, t(3)%maxt] > mt)) return
     nt = (t(1)%nc + ci - 1) / ci
@@ -719,7 +720,7 @@ contains
     ok = .false.
     if (s%ndim /= 3 .or. s%slab .or. s%ngrids < 2 .or. s%ms < 1) return
     if (s%lev(1)%g%all_neumann /= 0) return
-    if (mod(s%lev(1)%n(1), 2) /= 0 .or. any(s%lev(1)%n(1:2) < 16) .or. s%lev(1)%n(3) < 8) return
+    if (any(s%lev(1)%n(1:2) < 16) .or. s%lev(1)%n(3) < 8) return
     if (s%lev(1)%npts < 2_ik * 1024_ik * 1024_ik) return
     call get_environment_variable("NDSM_HIP_NO_TRACK", status=st)
     if (st == 0) return

@@ -11,7 +11,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 for c in range(ncase):
-    ns = [2 * int(rng.integers(8, 150)), int(rng.integers(16, 200)), int(rng.integers(8, 120))]
+    ns = [int(rng.integers(16, 300)), int(rng.integers(16, 200)), int(rng.integers(8, 120))]
     bcs = "".join(rng.choice(["D", "N"]) for _ in range(6))
     if bcs == "NNNNNN":
         bcs = "DNNNNN"

@@ -13,8 +13,8 @@ ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 bad = 0
 for c in range(ncase):
     while True:
-        ns = [2 * int(rng.integers(75, 140)), int(rng.integers(150, 230)), int(rng.integers(150, 210))]
-        if ns[0] * ns[1] * ns[2] >= 6.4e6:
+        ns = [int(rng.integers(100, 280)), int(rng.integers(100, 230)), int(rng.integers(100, 210))]
+        if ns[0] * ns[1] * ns[2] >= 2.2e6:
             break
     bcs = "".join(rng.choice(["D", "N"]) for _ in range(6))
     if bcs == "NNNNNN":

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, ndsm_amd
 from ndsm_amd import _lib
 L = ndsm_amd.load_library(); assert L.ndsm_hip_init(0) == 0
-for n in (128, 160, 192, 256, 384, 512):
+for n in [int(a) for a in sys.argv[1:]] or (128, 160, 192, 256, 384, 512):
     mesh = [np.linspace(0, 1, n)] * 3
     S = _lib.MGSolver([n, n, n], mesh, "NDDNDD"); S.zero_rhs()
     S.upload(1, _lib.BUF_U, np.random.default_rng(1).uniform(-1, 1, (n, n, n)))

@@ -107,10 +107,11 @@ def test_transfer3d_bitwise(hip, port, ns):
     S.close()
 
 
-@pytest.mark.parametrize("ns", ([128, 128, 128], [200, 100, 120], [256, 192, 160]), ids=_tag)
+@pytest.mark.parametrize("ns", ([128, 128, 128], [200, 100, 120], [256, 192, 160], [129, 128, 130], [257, 161, 158]), ids=_tag)
 def test_large_level_kernels_bitwise(hip, port, ns):
-    """the kernels that only serve large levels - temporally blocked fused smoother, LDS-streamed
-    restriction, LDS-tiled prolongation, fused residual+restriction - against the oracle, level 1 -> 2"""
+    """the kernels that only serve large levels - temporally blocked fused smoother (odd nx: its
+    ghost-column variant), LDS-streamed restriction, LDS-tiled prolongation, fused residual+restriction -
+    against the oracle, level 1 -> 2"""
     mesh = uniform_mesh(ns)
     shp = tuple(ns[::-1])
     u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
@@ -158,7 +159,8 @@ def test_large_level_kernels_bitwise(hip, port, ns):
     S.close()
 
 
-@pytest.mark.parametrize("ns", ([22, 22, 22], [40, 24, 32], [64, 64, 64], [200, 100, 70], [256, 192, 160]), ids=_tag)
+@pytest.mark.parametrize("ns", ([22, 22, 22], [40, 24, 32], [33, 22, 27], [64, 64, 64], [200, 100, 70], [199, 101, 70],
+                                [256, 192, 160]), ids=_tag)
 def test_sweep_plus_residual_launch_bitwise(hip, ns):
     """the pipeline stage that evaluates r = rhs - L u behind the last sweep (op 9, forced) returns the
     bits of sweeps-then-residual.hip (which test_kernels3d_bitwise pins to the oracle): every BC set,
@@ -469,7 +471,7 @@ def test_mixed_precision_solve(hip, ns):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ns,ms", (([256, 192, 160], 5), ([192, 192, 192], 4), ([256, 256, 256], 1)), ids=str)
+@pytest.mark.parametrize("ns,ms", (([256, 192, 160], 5), ([192, 192, 192], 4), ([256, 256, 256], 1), ([257, 161, 158], 5), ([193, 190, 131], 2)), ids=str)
 def test_fused_metric_bitwise(hip, ns, ms):
     """mg_solve on a large level 1 keeps the start-of-cycle iterate in place (three rotating buffers)
     and lets the launch of the cycle's last sweep evaluate update_u's max|u_new - u_old|
@@ -499,6 +501,31 @@ def test_fused_metric_bitwise(hip, ns, ms):
             a, b = out
             assert a[:4] == b[:4], (bcs, laplace, a[:4], b[:4])
             assert np.array_equal(a[4], b[4]), (bcs, laplace)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns", ([161, 120, 115], [160, 121, 115]), ids=_tag)
+def test_tracked_solve_vs_oracle(hip, port, ns):
+    """a level 1 just large enough for every large-level path at once (fused smoother incl. its odd-nx
+    ghost-column variant, sweep+residual, streamed restriction, prolongation and metric folded into the
+    smoother launches) - three solve-loop cycles against the oracle: du history and solution bits"""
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u0, rhs = rand_field(shp, 21), rand_field(shp, 22) * 10.0
+    for bcs, lap in (("NDDNDD", True), ("DNDDDN", False)):
+        r = np.zeros(shp) if lap else rhs
+        ie2, u2, du2, h2, nc2, _sw = port.solve_bvp(u0.copy(), r, mesh, bcs, ms=5, nmax=3, hist_len=8)
+        S = hip.MGSolver(ns, mesh, bcs, ms=5)
+        if lap:
+            S.zero_rhs()
+        else:
+            S.upload(1, hip.BUF_RHS, rhs)
+        S.upload(1, hip.BUF_U, u0)
+        ie, du, nc, h = S.solve(vc_tol=1e-10, nmax=3, hist_len=8)
+        got = S.download(1, hip.BUF_U)
+        S.close()
+        assert nc == nc2 == 3 and list(h) == list(h2[:3]), (bcs, list(h), list(h2[:3]))
+        assert np.array_equal(got, u2), bcs
 
 
 @pytest.mark.gpu
@@ -675,10 +702,10 @@ def test_argument_errors_are_reported_not_fatal(hip):
     with pytest.raises(hip.NdsmHipError):
         S.op(hip.OP_RELAX, S.ngrids + 1, 1)
     S.close()
-    S = hip.MGSolver([23, 24, 24], uniform_mesh([23, 24, 24]), "NDDNDD")     # odd nx: no x-pairs
+    S = hip.MGSolver([12, 24, 24], uniform_mesh([12, 24, 24]), "NDDNDD")     # rows shorter than the fused tile's minimum
     with pytest.raises(hip.NdsmHipError):
         S.op(hip.OP_RELAX_FUSED, 1, 1)
-    S.upload(1, hip.BUF_U, rand_field((24, 24, 23), 3))
+    S.upload(1, hip.BUF_U, rand_field((24, 24, 12), 3))
     S.op(hip.OP_RELAX, 1, 1)                                                 # the two-pass kernel takes it
     S.close()
     # the reference's only input check: fewer than two points -> ierr = 1, nothing else touched
@@ -721,8 +748,8 @@ def test_random_shapes_fused_launches(hip):
     and without a right-hand side: the forced fused launches (and the sweep+residual launch) return the
     bits of the two-pass kernels + residual.hip (scripts/fuzz_fused.py)"""
     rng = np.random.default_rng(20260102)
-    for c in range(20):
-        ns = [2 * int(rng.integers(8, 150)), int(rng.integers(16, 200)), int(rng.integers(8, 120))]
+    for c in range(30):
+        ns = [int(rng.integers(16, 300)), int(rng.integers(16, 200)), int(rng.integers(8, 120))]
         bcs = "".join(rng.choice(["D", "N"]) for _ in range(6))
         if bcs == "NNNNNN":
             bcs = "DNNNNN"
