@@ -185,7 +185,7 @@ contains
                minval(w%plan(:)%ck1 - w%plan(:)%ck0) >= 16
       end if
       ! the coarse slabs run on the fused smoother, and the coarse hierarchy must be the same
-      dist = dist .and. mod(n2(1), 2) == 0 .and. all(n2(1:2) >= 16) .and. ndsm_level_count(3, n2) >= ng - 1
+      dist = dist .and. all(n2(1:2) >= 16) .and. ndsm_level_count(3, n2) >= ng - 1
       if (dist) then
         allocate (cpart(0:nranks))
         cpart(0) = 0

@@ -12,7 +12,7 @@ ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 bad = done = 0
 while done < ncase:
     nr = int(rng.integers(2, 9))
-    ns = [2 * int(rng.integers(8, 80)), int(rng.integers(16, 120)), int(rng.integers(16, 60)) * nr]
+    ns = [int(rng.integers(16, 160)), int(rng.integers(16, 120)), int(rng.integers(16, 60)) * nr]
     lv = int(rng.integers(1, 4))
     bcs = "".join(rng.choice(["D", "N"]) for _ in range(6))
     if bcs == "NNNNNN":

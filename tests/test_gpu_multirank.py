@@ -97,7 +97,7 @@ def test_ranks_on_one_gpu_bitwise(hip, tmp_path, world):
     cases = [
         {"ns": [64, 48, 96], "bcs": "NDDNDD"},
         {"ns": [64, 48, 96], "bcs": "DDNDDN", "env": {"NDSM_HIP_OVERLAP": "0"}},
-        {"ns": [66, 40, 72], "bcs": "DNDDND", "laplace": True},
+        {"ns": [67, 40, 72], "bcs": "DNDDND", "laplace": True},
     ]
     out = _run_world(tmp_path, world, cases)
     _check_against_single(hip, out, world, cases)

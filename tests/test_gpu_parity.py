@@ -788,7 +788,7 @@ def test_random_slab_worlds(hip):
     try:
         while done < 12:
             nr = int(rng.integers(2, 9))
-            ns = [2 * int(rng.integers(8, 80)), int(rng.integers(16, 120)), int(rng.integers(16, 60)) * nr]
+            ns = [int(rng.integers(16, 160)), int(rng.integers(16, 120)), int(rng.integers(16, 60)) * nr]
             lv = int(rng.integers(1, 4))
             bcs = "".join(rng.choice(["D", "N"]) for _ in range(6))
             if bcs == "NNNNNN":
