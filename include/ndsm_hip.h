@@ -155,6 +155,20 @@ int ndsm_hip_dist_finalize(void);
 int ndsm_hip_slab_plan(const int *nshape, const double *x, const double *y, const double *z, int ngrids,
                        int nranks, int *out /* [nranks][12] */);
 
+/* ndsm_vector_solve on the z-slab decomposition (BASELINE config[4]: 2048 x 2048 x 1024 across the
+ * GPUs of a node).  Collective: every rank of the communicator calls it with the GLOBAL nshape4 =
+ * [nx,ny,nz,3] and mesh vectors and with ITS planes [z0, z1) of A and B - the split
+ * ndsm_hip_slab_plan reports for (nshape, ngrids = ioptc[get_iopt_ngrids()], nranks) - laid out
+ * (nx, ny, z1-z0, 3) in Fortran order.  The O(N^(2/3)) face phase (fluxes, six 2-D solves, tangential
+ * data) runs on rank 0 exactly as in ndsm_vector_solve, the three 3-D solves on z-slab worlds, flux
+ * balance and curl on the slabs.  Options, return value and the contents of A (in: initial guess,
+ * out: vector potential) and B (in: boundary normal component, out: curl A + correction) as for
+ * ndsm_vector_solve - the same bits on the same input.  fp64 only (get_iopt_prec() must be 0);
+ * nranks == 1 is ndsm_vector_solve.  Reference: none (shared-memory OpenMP only); pipeline of
+ * ndsm_vector_potential.f90:130-497. */
+int ndsm_hip_world_vector_solve(int rank, int nranks, const int nshape4[4], int ioptc[16], double ropt[16],
+                                const double *x, const double *y, const double *z, double *A_slab, double *B_slab);
+
 /* rank >= 0: this process holds slab `rank` (RCCL transport, after ndsm_hip_dist_init);
  * rank <  0: loop-back world - all nranks slabs on this GPU, neighbours reached by device copies
  *            (verification of the slab algebra on one GPU). */

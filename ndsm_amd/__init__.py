@@ -6,9 +6,9 @@ loader that mirrors the reference's ndsm.py, and thin ctypes wrappers for the
 additive C entry points.  There is no CPU fallback: without the library or
 without an MI355X every call raises.
 """
-from .ndsm import vector_potential, get_lib_path  # noqa: F401
+from .ndsm import vector_potential, vector_potential_slab, get_lib_path  # noqa: F401
 from ._lib import (load_library, lib_path, MGSolver, World, slab_plan, poisson_solve,  # noqa: F401
                    NdsmHipError)
 
-__all__ = ["vector_potential", "get_lib_path", "load_library", "lib_path", "MGSolver", "poisson_solve",
+__all__ = ["vector_potential", "vector_potential_slab", "get_lib_path", "load_library", "lib_path", "MGSolver", "poisson_solve",
            "NdsmHipError"]

@@ -136,6 +136,11 @@ int ndsmk_solve_exact(const ndsmk_grid *g, double *u, const double *rhs, double 
 int ndsmk_balance_curl(double *A, double *B, const int32_t *n3, const double *x, const double *y,
                        const double *z, const double *h_phi6, const double *h_span3,
                        const double *h_dq3, int curl_first);
+/* the same on a z-slab: A (nx,ny,na,3) holds global planes [kg0, kg0+na) - one ghost plane per
+ * neighbour -, B (nx,ny,nb,3) starts at A's local plane boff; n3 and x,y,z stay GLOBAL */
+int ndsmk_balance_curl_slab(double *A, double *B, const int32_t *n3, int kg0, int na, int nb, int boff,
+                            const double *x, const double *y, const double *z, const double *h_phi6,
+                            const double *h_span3, const double *h_dq3, int curl_first);
 
 /* level-1 form for the V-cycle driver: three buffers (u on entry + two spares), `keep` (one of them
  * or NULL) is never written, *where = 0/1/2 names the buffer holding the result.  r: residual of the

@@ -13,9 +13,13 @@
 
 namespace {
 
+// A and B may be z-slabs of the global field (ndsmh_wvecpot): A holds planes [kg0, kg0 + na) of the
+// global nz, B the nb planes that start at A's local plane boff (A carries a ghost plane per
+// neighbour for the z differences).  Single domain: kg0 = boff = 0, na = nb = nz.
 struct PostArgs {
-  int n[3];
-  const double *x, *y, *z;  // device mesh vectors
+  int n[3];                 // GLOBAL shape
+  int kg0, na, nb, boff;
+  const double *x, *y, *z;  // device mesh vectors (global)
   double phi[6];
   double span[3];
   double dq[3];
@@ -25,13 +29,13 @@ template <bool WITH_B>
 __global__ __launch_bounds__(256) void balance_k(double *__restrict__ A, double *__restrict__ B, PostArgs p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
+  const int k = blockIdx.z;  // local plane of A
   if (i >= p.n[0] || j >= p.n[1]) return;
-  const size_t N = (size_t)p.n[0] * p.n[1] * p.n[2];
+  const size_t N = (size_t)p.n[0] * p.n[1] * p.na, NB = (size_t)p.n[0] * p.n[1] * p.nb;
   const size_t c = (size_t)i + (size_t)p.n[0] * ((size_t)j + (size_t)p.n[1] * (size_t)k);
   const double vol = p.span[0] * p.span[1] * p.span[2];
   const double g1 = (p.phi[1] - p.phi[0]) / vol, g2 = (p.phi[3] - p.phi[2]) / vol, g3 = (p.phi[5] - p.phi[4]) / vol;
-  const double x = p.x[i], y = p.y[j], z = p.z[k];
+  const double x = p.x[i], y = p.y[j], z = p.z[p.kg0 + k];
   const double third = 1.0 / 3.0;
   // :927-929
   const double b1 = g1 * x + p.phi[0] * p.span[0] / vol;
@@ -45,10 +49,11 @@ __global__ __launch_bounds__(256) void balance_k(double *__restrict__ A, double 
   const double cy = -(p.phi[0] * p.span[0] * z / vol);
   const double cz = -(p.phi[2] * p.span[1] * x / vol);
   // :942-943
-  if (WITH_B) {
-    B[c] = B[c] + b1;
-    B[c + N] = B[c + N] + b2;
-    B[c + 2 * N] = B[c + 2 * N] + b3;
+  if (WITH_B && k >= p.boff && k < p.boff + p.nb) {
+    const size_t cb = c - (size_t)p.n[0] * p.n[1] * (size_t)p.boff;
+    B[cb] = B[cb] + b1;
+    B[cb + NB] = B[cb + NB] + b2;
+    B[cb + 2 * NB] = B[cb + 2 * NB] + b3;
   }
   A[c] = A[c] + cx + third * (l1x + l2x + l3x);
   A[c + N] = A[c + N] + cy + third * (l1y + l2y + l3y);
@@ -77,33 +82,47 @@ __device__ __forceinline__ double ddq(const double *__restrict__ v, size_t c, in
 __global__ __launch_bounds__(256) void curl_k(const double *__restrict__ A, double *__restrict__ B, PostArgs p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
+  const int kb = blockIdx.z;          // local plane of B
   if (i >= p.n[0] || j >= p.n[1]) return;
   const size_t sy = (size_t)p.n[0], sz = (size_t)p.n[0] * p.n[1];
-  const size_t N = sz * p.n[2];
+  const size_t N = sz * p.na, NB = sz * p.nb;
+  const int k = kb + p.boff;          // local plane of A
+  const int kg = p.kg0 + k;           // global plane: decides between centred and one-sided z differences
   const size_t c = (size_t)i + sy * (size_t)j + sz * (size_t)k;
+  const size_t cb = (size_t)i + sy * (size_t)j + sz * (size_t)kb;
   const double *Ax = A, *Ay = A + N, *Az = A + 2 * N;
   const double axy = ddq(Ax, c, j, p.n[1], sy, p.dq[1]);
-  const double axz = ddq(Ax, c, k, p.n[2], sz, p.dq[2]);
+  const double axz = ddq(Ax, c, kg, p.n[2], sz, p.dq[2]);
   const double ayx = ddq(Ay, c, i, p.n[0], 1, p.dq[0]);
-  const double ayz = ddq(Ay, c, k, p.n[2], sz, p.dq[2]);
+  const double ayz = ddq(Ay, c, kg, p.n[2], sz, p.dq[2]);
   const double azx = ddq(Az, c, i, p.n[0], 1, p.dq[0]);
   const double azy = ddq(Az, c, j, p.n[1], sy, p.dq[1]);
-  B[c] = azy - ayz;          // :802-804
-  B[c + N] = axz - azx;
-  B[c + 2 * N] = ayx - axy;
+  B[cb] = azy - ayz;          // :802-804
+  B[cb + NB] = axz - azx;
+  B[cb + 2 * NB] = ayx - axy;
 }
 
 }  // namespace
 
-// A, B: device arrays (nx,ny,nz,3).  x,y,z: DEVICE mesh vectors.  curl_first
-// != 0 selects the reference's IOPT_FLXCRL == 1 order (:455-465).
-extern "C" int ndsmk_balance_curl(double *A, double *B, const int32_t *n3, const double *x, const double *y,
-                                  const double *z, const double *h_phi6, const double *h_span3,
-                                  const double *h_dq3, int curl_first) {
+// A: device array (nx,ny,na,3) holding global planes [kg0, kg0 + na); B: (nx,ny,nb,3), its plane 0
+// = A's local plane boff.  x,y,z: DEVICE mesh vectors of the GLOBAL grid n3.  curl_first != 0
+// selects the reference's IOPT_FLXCRL == 1 order (:455-465).  The flux-balance fields are added to
+// every plane of A (ghosts included: the curl that follows differentiates them).
+extern "C" int ndsmk_balance_curl_slab(double *A, double *B, const int32_t *n3, int kg0, int na, int nb, int boff,
+                                       const double *x, const double *y, const double *z, const double *h_phi6,
+                                       const double *h_span3, const double *h_dq3, int curl_first) {
   NDSM_REQUIRE_READY();
   NDSM_CHECK_ARG(n3[0] >= 3 && n3[1] >= 3 && n3[2] >= 3);  // one-sided stencils need three points
+  NDSM_CHECK_ARG(kg0 >= 0 && na >= 1 && kg0 + na <= n3[2] && nb >= 1 && boff >= 0 && boff + nb <= na);
+  // the z stencil of every B plane must lie inside A: centred needs a plane either side,
+  // the one-sided ones at the global ends three planes inwards
+  NDSM_CHECK_ARG((kg0 + boff == 0 ? na - boff >= 3 : boff >= 1) &&
+                 (kg0 + boff + nb == n3[2] ? boff + nb >= 3 : boff + nb < na));
   PostArgs p;
+  p.kg0 = kg0;
+  p.na = na;
+  p.nb = nb;
+  p.boff = boff;
   for (int d = 0; d < 3; ++d) {
     p.n[d] = n3[d];
     p.span[d] = h_span3[d];
@@ -114,20 +133,27 @@ extern "C" int ndsmk_balance_curl(double *A, double *B, const int32_t *n3, const
   p.y = y;
   p.z = z;
   dim3 block(64, 4, 1);
-  dim3 grid((n3[0] + 63) / 64, (n3[1] + 3) / 4, n3[2]);
+  dim3 grida((n3[0] + 63) / 64, (n3[1] + 3) / 4, na), gridb((n3[0] + 63) / 64, (n3[1] + 3) / 4, nb);
   hipStream_t s = ndsm::stream();
   if (curl_first) {
-    hipLaunchKernelGGL(curl_k, grid, block, 0, s, A, B, p);
+    hipLaunchKernelGGL(curl_k, gridb, block, 0, s, A, B, p);
     NDSM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(balance_k<true>, grid, block, 0, s, A, B, p);
+    hipLaunchKernelGGL(balance_k<true>, grida, block, 0, s, A, B, p);
     NDSM_LAUNCH_CHECK();
   } else {
     // the reference also adds the linear field to B here (:474), but its curl
     // (:475) then overwrites all of B: that dead update is skipped
-    hipLaunchKernelGGL(balance_k<false>, grid, block, 0, s, A, B, p);
+    hipLaunchKernelGGL(balance_k<false>, grida, block, 0, s, A, B, p);
     NDSM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(curl_k, grid, block, 0, s, A, B, p);
+    hipLaunchKernelGGL(curl_k, gridb, block, 0, s, A, B, p);
     NDSM_LAUNCH_CHECK();
   }
   return 0;
+}
+
+// the whole field in one piece
+extern "C" int ndsmk_balance_curl(double *A, double *B, const int32_t *n3, const double *x, const double *y,
+                                  const double *z, const double *h_phi6, const double *h_span3,
+                                  const double *h_dq3, int curl_first) {
+  return ndsmk_balance_curl_slab(A, B, n3, 0, n3[2], n3[2], 0, x, y, z, h_phi6, h_span3, h_dq3, curl_first);
 }

@@ -21,6 +21,7 @@ module ndsmh_cabi
   use ndsmh_mg
   use ndsmh_world
   use ndsmh_vecpot
+  use ndsmh_wvecpot
   implicit none
   private
 
@@ -123,6 +124,64 @@ contains
     ioptc = int(iopt, c_int)
     if (rc /= 0) then
       call report("ndsm_vector_solve", rc)
+      ioptc(IOPT_IERR) = rc
+      ierr = rc
+    else
+      ierr = int(iopt(IOPT_IERR), c_int)
+    end if
+  end function
+
+  ! The same call on a z-slab decomposition (additive; BASELINE config[4]): one process per GPU,
+  ! every rank of the communicator (ndsm_hip_dist_init) calls it with the GLOBAL nshape4 and mesh
+  ! and with ITS planes [z0, z1) of A and B - the split ndsm_hip_slab_plan reports - laid out
+  ! (nx, ny, z1-z0, 3).  Options, return value and the contents of A and B as for
+  ! ndsm_vector_solve; nranks == 1 is ndsm_vector_solve.
+  function ndsm_hip_world_vector_solve(rank, nranks, nshape4, ioptc, ropt, x, y, z, A, B) &
+      bind(c, name="ndsm_hip_world_vector_solve") result(ierr)
+    integer(c_int), value :: rank, nranks
+    integer(c_int), intent(in) :: nshape4(4)
+    integer(c_int), intent(inout) :: ioptc(0:OPT_LEN - 1)
+    real(c_double), intent(inout) :: ropt(0:OPT_LEN - 1)
+    real(c_double), intent(in) :: x(nshape4(1)), y(nshape4(2)), z(nshape4(3))
+    type(c_ptr), value :: A, B
+    integer(c_int) :: ierr
+    integer(ik) :: iopt(0:OPT_LEN - 1)
+    integer(c_int32_t) :: n3(3)
+    real(c_double) :: t0
+    real(c_double), pointer, contiguous :: A4(:, :, :, :), B4(:, :, :, :)
+    type(slab_t), allocatable :: plan(:)
+    integer(c_int) :: rc
+    integer :: nzl
+
+    iopt = ioptc
+    verbose = (iopt(IOPT_DEBUG) == 1)
+    t0 = wall_seconds()
+    n3 = nshape4(1:3)
+    ierr = NDSMK_EARG
+    if (nshape4(4) /= 3 .or. nranks < 1 .or. rank < 0 .or. rank >= nranks) return
+    if (.not. c_associated(A) .or. .not. c_associated(B)) return
+    rc = ndsmk_init(-1_c_int)
+    if (rc == 0) then
+      if (nranks == 1) then
+        call c_f_pointer(A, A4, [int(n3(1)), int(n3(2)), int(n3(3)), 3])
+        call c_f_pointer(B, B4, [int(n3(1)), int(n3(2)), int(n3(3)), 3])
+        rc = vecpot_solve(n3, iopt, ropt, x, y, z, A4, B4)
+      else if (any(n3 < 2)) then
+        iopt(IOPT_IERR) = 1
+      else
+        rc = world_plan_only(n3, x, y, z, int(iopt(IOPT_NGRIDS)), int(nranks), plan)
+        if (rc == 0) then
+          nzl = plan(rank)%z1 - plan(rank)%z0
+          call c_f_pointer(A, A4, [int(n3(1)), int(n3(2)), nzl, 3])
+          call c_f_pointer(B, B4, [int(n3(1)), int(n3(2)), nzl, 3])
+          rc = wvecpot_solve(n3, iopt, ropt, x, y, z, int(nranks), int(rank), A4, B4)
+        end if
+      end if
+    end if
+    ropt(ROPT_TIM) = wall_seconds() - t0
+    ioptc = int(iopt, c_int)
+    if (rc /= 0) then
+      call report("ndsm_hip_world_vector_solve", rc)
       ioptc(IOPT_IERR) = rc
       ierr = rc
     else

@@ -273,6 +273,17 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_balance_curl_slab(A, B, n3, kg0, na, nb, boff, x, y, z, phi6, span3, dq3, curl_first) &
+        bind(c, name="ndsmk_balance_curl_slab") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: A, B, x, y, z
+      integer(c_int32_t), intent(in) :: n3(3)
+      integer(c_int), value :: kg0, na, nb, boff
+      real(c_double), intent(in) :: phi6(6), span3(3), dq3(3)
+      integer(c_int), value :: curl_first
+      integer(c_int) :: rc
+    end function
+
   end interface
 
 contains

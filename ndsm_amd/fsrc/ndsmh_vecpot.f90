@@ -31,6 +31,8 @@ module ndsmh_vecpot
   private
 
   public :: vecpot_solve, poisson_solve
+  ! pieces the distributed driver (ndsmh_wvecpot) shares with vecpot_solve
+  public :: face_data, face_axis, face_upper, face_t1, face_t2, face_order, face_copy, vecpot_faces, say
   public :: OPT_LEN, IOPT_MS, IOPT_NCYCLES, IOPT_FACE1, IOPT_IERR, IOPT_FLXCRL, IOPT_DEBUG, IOPT_DUMAX, &
             IOPT_NMAXEX, IOPT_FAIL3D, IOPT_NGRIDS, IOPT_NCYC_OUT, IOPT_PREC, ROPT_VTOL, ROPT_CTOL, ROPT_TIM, ROPT_DULAST
   public :: verbose
@@ -58,6 +60,10 @@ module ndsmh_vecpot
   ! A_t = -grad(chi) x n projected on (t1, t2):  (s1*dchi/dt2, s2*dchi/dt1)
   real(wp), parameter :: at_s1(6) = [-1, -1, +1, +1, -1, -1]
   real(wp), parameter :: at_s2(6) = [+1, +1, -1, -1, +1, +1]
+
+  ! the four faces that carry tangential data of component c, in the order the reference writes them
+  ! (:647-650, :663-666, :679-682; later writes win on shared edges)
+  integer, parameter :: face_order(4, 3) = reshape([3, 4, 5, 6, 1, 2, 5, 6, 1, 2, 3, 4], [4, 3])
 
   type :: face_data
     integer :: n1 = 0, n2 = 0
@@ -138,6 +144,97 @@ contains
   end function
 
   ! ------------------------------------------------------------------
+  ! Steps 1b-3 of the pipeline, on whole faces: fluxes of fc(:)%bn (:283-306), the six 2-D
+  ! all-Neumann solves on the device (:338-365) and the tangential data A_t = -grad(chi) x n
+  ! (:387-399, :977-1031).  In: fc(f)%bn (allocated with chi, at1, at2).  Out: phi, fc(f)%at1/at2,
+  ! ierr2d = flag of the LAST face solve (Q3').
+  ! ------------------------------------------------------------------
+  function vecpot_faces(iopt, ropt, qx, qy, qz, dq, span, fc, phi, ierr2d) result(rc)
+    integer(ik), intent(in) :: iopt(0:OPT_LEN - 1)
+    real(wp), intent(in) :: ropt(0:OPT_LEN - 1)
+    real(wp), intent(in), target :: qx(:), qy(:), qz(:)
+    real(wp), intent(in) :: dq(3), span(3)
+    type(face_data), intent(inout), target :: fc(6)
+    real(wp), intent(out) :: phi(6)
+    integer, intent(out) :: ierr2d
+    integer(c_int) :: rc
+    character(len=*), parameter :: me = "compute_vector_potential"
+    type(mg_solver) :: s2
+    real(wp) :: area(6), du_last, fac
+    integer :: f, i, j, ncyc, pair
+    integer(ik) :: sweeps, bad
+    integer(c_int32_t) :: fshape(3)
+    logical :: live2
+    character(len=1) :: bc2(4)
+    real(wp), pointer :: qa(:), qb(:)
+
+    rc = 0
+    live2 = .false.
+    do f = 1, 6
+      phi(f) = trapezoid(fc(f)%bn, dq(1), dq(2))            ! Q4
+    end do
+    area = [span(2) * span(3), span(2) * span(3), span(1) * span(3), span(1) * span(3), &
+            span(1) * span(2), span(1) * span(2)]
+
+    ! ---- 2. chi on every face: 2-D all-Neumann solves on the device ---
+    call say(me, "Solve BVP on each boundary...")
+    ierr2d = 0
+    bc2 = 'N'
+    do pair = 1, 3
+      f = 2 * pair - 1
+      qa => axis_mesh(face_t1(f)); qb => axis_mesh(face_t2(f))
+      fshape = [int(fc(f)%n1, c_int32_t), int(fc(f)%n2, c_int32_t), 1_c_int32_t]
+      rc = mg_create(s2, 2, fshape, qa, qb, qb, bc2, int(iopt(IOPT_NGRIDS))); live2 = .true.
+      if (rc /= 0) goto 900
+      s2%ms = int(iopt(IOPT_MS)); s2%ex_tol = ropt(ROPT_CTOL); s2%use_max = (iopt(IOPT_DUMAX) == 1)
+      s2%nmax_exact = int(iopt(IOPT_NMAXEX))
+      do f = 2 * pair - 1, 2 * pair
+        fc(f)%chi = 0
+        fc(f)%bn = fc(f)%bn - phi(f) / area(f)
+        rc = mg_set_u(s2, c_loc(fc(f)%chi)); if (rc /= 0) goto 900
+        rc = mg_set_rhs(s2, c_loc(fc(f)%bn)); if (rc /= 0) goto 900
+        rc = mg_reset_info(s2); if (rc /= 0) goto 900
+        rc = mg_solve(s2, ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du_last, ncyc, ierr2d)
+        if (rc /= 0) goto 900
+        rc = mg_get_u(s2, c_loc(fc(f)%chi)); if (rc /= 0) goto 900
+        if (ierr2d /= 0) print *, "Warning: IOPT_NCYCLES exceeded. V-cycle iteration may not have converged"
+        if (mg_read_info(s2, sweeps, bad) == 0) then
+          if (bad > 0) print *, "Warning: IOPT_NMAXEX exceeded. Coarse-mesh solution may not have converged"
+        end if
+      end do
+      call mg_destroy(s2); live2 = .false.
+    end do
+
+    ! ---- 3. A_t = -grad(chi) x n --------------------------------------
+    call say(me, "Compute vector potential boundary conditions...")
+    do f = 1, 6
+      fac = 1.0_wp / (2.0_wp * dq(face_axis(f)))            ! Q4: the normal spacing
+      do j = 1, fc(f)%n2
+        do i = 1, fc(f)%n1
+          call tangential(fc(f), f, i, j, fac)
+        end do
+      end do
+    end do
+
+900 continue
+    if (live2) call mg_destroy(s2)
+
+  contains
+
+    function axis_mesh(k) result(q)
+      integer, intent(in) :: k
+      real(wp), pointer :: q(:)
+      select case (k)
+      case (1); q => qx
+      case (2); q => qy
+      case default
+        q => qz
+      end select
+    end function
+
+  end function
+
+  ! ------------------------------------------------------------------
   ! The whole ndsm_vector_solve pipeline.  A, B: host arrays (nx,ny,nz,3).
   ! One 3-D solver (device arrays + transfer tables) serves Ax, Ay and Az; one
   ! 2-D solver serves the two faces of each axis.  A and B live in HBM from the
@@ -153,23 +250,21 @@ contains
 
     character(len=*), parameter :: me = "compute_vector_potential"
     type(face_data), target :: fc(6)
-    type(mg_solver) :: s2, s3
-    real(wp) :: dq(3), span(3), phi(6), area(6), du_last, fac
-    integer :: f, ax, c, i, j, lay, ierr2d, ierr3d, ncyc, ngr, pair
+    type(mg_solver) :: s3
+    real(wp) :: dq(3), span(3), phi(6), du_last
+    integer :: f, ax, c, i, lay, ierr2d, ierr3d, ncyc, ngr
     integer(ik) :: sweeps, bad, npts
-    integer(c_int32_t) :: fshape(3)
-    logical :: use_max, live2, live3
-    character(len=1) :: bc3(6), bc2(4)
-    real(wp), pointer :: comp(:, :, :), qa(:), qb(:)
+    logical :: use_max, live3
+    character(len=1) :: bc3(6)
+    real(wp), pointer :: comp(:, :, :)
     type(c_ptr) :: dA, dB, dmesh
     integer(c_size_t) :: nb, off_y, off_z
-    integer, parameter :: order(4, 3) = reshape([3, 4, 5, 6, 1, 2, 5, 6, 1, 2, 3, 4], [4, 3])
 
     rc = 0
     use_max = (iopt(IOPT_DUMAX) == 1)
     ngr = int(iopt(IOPT_NGRIDS))
     iopt(IOPT_FAIL3D) = 0
-    live2 = .false.; live3 = .false.
+    live3 = .false.
     dA = c_null_ptr; dB = c_null_ptr; dmesh = c_null_ptr
 
     ! :201-221 extent and spacing; fewer than two points is the reference's only input check
@@ -192,52 +287,13 @@ contains
       lay = merge(int(n3(ax)), 1, face_upper(f))
       comp => B(:, :, :, ax)
       call face_copy(comp, ax, lay, fc(f)%bn, to_face=.true.)
-      phi(f) = trapezoid(fc(f)%bn, dq(1), dq(2))            ! Q4
     end do
-    area = [span(2) * span(3), span(2) * span(3), span(1) * span(3), span(1) * span(3), &
-            span(1) * span(2), span(1) * span(2)]
-
-    ! ---- 2. chi on every face: 2-D all-Neumann solves on the device ---
-    call say(me, "Solve BVP on each boundary...")
-    ierr2d = 0
-    bc2 = 'N'
-    do pair = 1, 3
-      f = 2 * pair - 1
-      qa => axis_mesh(face_t1(f)); qb => axis_mesh(face_t2(f))
-      fshape = [int(fc(f)%n1, c_int32_t), int(fc(f)%n2, c_int32_t), 1_c_int32_t]
-      rc = mg_create(s2, 2, fshape, qa, qb, qb, bc2, ngr); live2 = .true.
-      if (rc /= 0) goto 900
-      s2%ms = int(iopt(IOPT_MS)); s2%ex_tol = ropt(ROPT_CTOL); s2%use_max = use_max
-      s2%nmax_exact = int(iopt(IOPT_NMAXEX))
-      do f = 2 * pair - 1, 2 * pair
-        fc(f)%chi = 0
-        fc(f)%bn = fc(f)%bn - phi(f) / area(f)
-        rc = mg_set_u(s2, c_loc(fc(f)%chi)); if (rc /= 0) goto 900
-        rc = mg_set_rhs(s2, c_loc(fc(f)%bn)); if (rc /= 0) goto 900
-        rc = mg_reset_info(s2); if (rc /= 0) goto 900
-        rc = mg_solve(s2, ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du_last, ncyc, ierr2d)
-        if (rc /= 0) goto 900
-        rc = mg_get_u(s2, c_loc(fc(f)%chi)); if (rc /= 0) goto 900
-        call warn_if_needed(s2, ierr2d)
-      end do
-      call mg_destroy(s2); live2 = .false.
-    end do
-
-    ! ---- 3. A_t = -grad(chi) x n --------------------------------------
-    call say(me, "Compute vector potential boundary conditions...")
-    do f = 1, 6
-      fac = 1.0_wp / (2.0_wp * dq(face_axis(f)))            ! Q4: the normal spacing
-      do j = 1, fc(f)%n2
-        do i = 1, fc(f)%n1
-          call tangential(fc(f), f, i, j, fac)
-        end do
-      end do
-    end do
+    rc = vecpot_faces(iopt, ropt, qx, qy, qz, dq, span, fc, phi, ierr2d)
+    if (rc /= 0) goto 900
 
     ! ---- 4. the three 3-D Laplace problems ----------------------------
     call say(me, "Solve BVP 3D...")
     rc = ndsmk_alloc(dA, 3_c_size_t * nb); if (rc /= 0) goto 900
-    rc = ndsmk_alloc(dB, 3_c_size_t * nb); if (rc /= 0) goto 900
     bc3 = 'D'; bc3(1) = 'N'; bc3(4) = 'N'
     rc = mg_create(s3, 3, n3, qx, qy, qz, bc3, ngr); live3 = .true.
     if (rc /= 0) goto 900
@@ -247,7 +303,7 @@ contains
     do c = 1, 3
       comp => A(:, :, :, c)
       do i = 1, 4
-        f = order(i, c)
+        f = face_order(i, c)
         lay = merge(int(n3(face_axis(f))), 1, face_upper(f))
         ! component c is the t1 direction of face f if t1 == c, else its t2 direction
         if (face_t1(f) == c) then
@@ -273,6 +329,8 @@ contains
       end if
     end do
     call mg_destroy(s3); live3 = .false.
+    ! B takes the memory the 3-D hierarchy has just returned: the peak is A + one hierarchy, not A + B + it
+    rc = ndsmk_alloc(dB, 3_c_size_t * nb); if (rc /= 0) goto 900
 
     ! ---- 5. flux balance + curl on the device (default order :467-477) -
     call say(me, "Compute B = curl(B) and flux correction...")
@@ -293,22 +351,10 @@ contains
     call say(me, "Deallocate memory...")
 
 900 continue
-    if (live2) call mg_destroy(s2)
     if (live3) call mg_destroy(s3)
     i = ndsmk_free(dA); i = ndsmk_free(dB); i = ndsmk_free(dmesh)
 
   contains
-
-    function axis_mesh(k) result(q)
-      integer, intent(in) :: k
-      real(wp), pointer :: q(:)
-      select case (k)
-      case (1); q => qx
-      case (2); q => qy
-      case default
-        q => qz
-      end select
-    end function
 
     subroutine warn_if_needed(sv, ie)
       type(mg_solver), intent(in) :: sv

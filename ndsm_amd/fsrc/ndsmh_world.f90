@@ -38,6 +38,7 @@ module ndsmh_world
 
   public :: mg_world, world_create, world_destroy, world_vcycle, world_solve, world_relax
   public :: world_upload, world_download, world_plan_only, world_set_params, world_dist_levels
+  public :: ndsmk_dist_group_start, ndsmk_dist_group_end, ndsmk_dist_send, ndsmk_dist_recv   ! for ndsmh_wvecpot
 
   interface
     function ndsmk_dist_size() bind(c, name="ndsmk_dist_size") result(n)

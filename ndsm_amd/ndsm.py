@@ -86,3 +86,44 @@ def vector_potential(x, y, z, b, niterex_max=10000, ncycles_max=1024, ex_tol=1e-
     bflat = b.flatten()
     ierr = lib.ndsm_vector_solve(ctypes.c_size_t(b.size), nshape, ioptc, ropt, x, y, z, apot, bflat)
     return ierr, apot.reshape(nshape[::-1]), bflat.reshape(nshape[::-1])
+
+
+def vector_potential_slab(x, y, z, b_slab, rank, nranks, niterex_max=10000, ncycles_max=1024, ex_tol=1e-13, vc_tol=1e-10,
+                          ms=5, mean=False, debug=False, a_init=None, lib=None):
+    """`vector_potential` on a z-slab decomposition (additive; BASELINE config[4]): one process per
+    GPU, called collectively by every rank of the communicator set up with `_lib.dist_init`.
+
+    x, y, z: the GLOBAL mesh vectors.  b_slab: this rank's planes of the field, shaped
+    (3, z1-z0, ny, nx), [z0, z1) being rank `rank`'s entry of `_lib.slab_plan([nx,ny,nz], mesh, nranks)`.
+    a_init: initial guess of the same shape (default zeros, as vector_potential passes).
+    Returns (ierr, A_slab, B_slab) - the same bits the single-GPU call returns for those planes."""
+    from . import _lib
+    L = lib or _lib.load_library()
+    b_slab = np.ascontiguousarray(b_slab, dtype=np.float64)
+    nzl = b_slab.shape[1]
+    nshape = np.array([len(x), len(y), len(z), 3], dtype=np.intc)
+    assert b_slab.shape == (3, nzl, len(y), len(x)), b_slab.shape
+    nopt = L.get_iopt_len()
+    ioptc = np.zeros(nopt, dtype=np.intc)
+    ropt = np.zeros(nopt, dtype=np.float64)
+    ioptc[L.get_iopt_ms()] = ms
+    ioptc[L.get_iopt_ncycles()] = ncycles_max
+    ioptc[L.get_iopt_iopt_nmaxex()] = niterex_max
+    ropt[L.get_ropt_vtol()] = vc_tol
+    ropt[L.get_ropt_ctol()] = ex_tol
+    ioptc[L.get_iopt_debug()] = L.get_iopt_true() if debug else L.get_iopt_false()
+    ioptc[L.get_iopt_dumax()] = L.get_iopt_false() if mean else L.get_iopt_true()
+    apot = np.zeros(b_slab.size) if a_init is None else np.ascontiguousarray(a_init, dtype=np.float64).flatten()
+    assert apot.size == b_slab.size
+    bflat = b_slab.flatten()
+    xs, ys, zs = (np.ascontiguousarray(v, dtype=np.float64) for v in (x, y, z))
+    dp = ctypes.POINTER(ctypes.c_double)
+    ip = ctypes.POINTER(ctypes.c_int)
+    L.ndsm_hip_world_vector_solve.restype = ctypes.c_int
+    L.ndsm_hip_world_vector_solve.argtypes = [ctypes.c_int, ctypes.c_int, ip, ip, dp, dp, dp, dp, dp, dp]
+    ierr = L.ndsm_hip_world_vector_solve(int(rank), int(nranks), nshape.ctypes.data_as(ip), ioptc.ctypes.data_as(ip),
+                                         ropt.ctypes.data_as(dp), xs.ctypes.data_as(dp), ys.ctypes.data_as(dp),
+                                         zs.ctypes.data_as(dp), apot.ctypes.data_as(dp), bflat.ctypes.data_as(dp))
+    if ierr >= 9000:
+        raise NdsmHipError(f"ndsm_hip_world_vector_solve failed with code {ierr}: {_lib.last_error(L)}")
+    return ierr, apot.reshape(b_slab.shape), bflat.reshape(b_slab.shape)

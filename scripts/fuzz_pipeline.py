@@ -1,0 +1,28 @@
+"""random shapes / options / fields: ndsm_vector_solve on the GPU vs the oracle port (dev aid)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import ndsm_amd
+from oracle import Oracle
+from golden_inputs import analytic_case, uniform_mesh
+port = Oracle("port")
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+bad = 0
+for c in range(ncase):
+    ns = [int(rng.integers(5, 60)) for _ in range(3)]
+    x, y, z, A1, b = analytic_case(ns)
+    if rng.integers(0, 2):
+        b = b + 0.3 * rng.uniform(-1, 1, b.shape)       # not current free, fluxes do not balance
+    kw = dict(ms=int(rng.integers(1, 6)), mean=bool(rng.integers(0, 2)), ncycles_max=int(rng.choice([1, 3, 1024])),
+              vc_tol=float(rng.choice([1e-10, 1e-7])))
+    ierr, A, B = ndsm_amd.vector_potential(x, y, z, b.copy(), **kw)
+    ierr2, A2, B2, _, _ = port.vector_potential(x, y, z, b, **kw)
+    sc = max(np.abs(A2).max(), 1e-300)
+    h = x[1] - x[0]
+    ea, eb = np.abs(A - A2).max() / sc, np.abs(B - B2).max() / (sc * 4 / h)
+    ok = ierr == ierr2 and ea <= 1e-11 and eb <= 1e-11
+    print(("ok  " if ok else "BAD ") + f"{ns} {kw} ierr {ierr}/{ierr2} dA {ea:.1e} dB {eb:.1e}", flush=True)
+    bad += not ok
+print(f"{ncase} cases, {bad} mismatches")
