@@ -15,6 +15,9 @@ with tempfile.TemporaryDirectory() as d:
     t = time.time()
     out = T._run_world(d, world, cases, timeout=900, worker="multirank_vecpot_worker.py")
     print(f"{world} ranks, {n}^3: {time.time()-t:.1f} s wall incl. process start", flush=True)
+    for r in (0, world - 1):
+        print(f"--- rank {r}")
+        print("".join(l for l in open(os.path.join(out, f"rank{r}.log")) if "TIMING" in l))
     x, y, z, A1, b = analytic_case([n, n, n])
     ierr, A, B = ndsm_amd.vector_potential(x, y, z, b.copy())
     gA = np.concatenate([np.load(os.path.join(out, f"v0_A_r{r}.npy")) for r in range(world)], axis=1)

@@ -50,6 +50,9 @@ def _run_world(tmp_path, world, cases, timeout=300, worker="multirank_worker.py"
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    for i, l in enumerate(logs):
+        with open(os.path.join(out, f"rank{i}.log"), "w") as f:
+            f.write(l)
     assert all(c == 0 for c in codes), "\n".join(f"--- rank {i} rc {c}\n{l[-3000:]}" for i, (c, l) in enumerate(zip(codes, logs)))
     return out
 
