@@ -163,8 +163,9 @@ int ndsm_hip_slab_plan(const int *nshape, const double *x, const double *y, cons
  * data) runs on rank 0 exactly as in ndsm_vector_solve, the three 3-D solves on z-slab worlds, flux
  * balance and curl on the slabs.  Options, return value and the contents of A (in: initial guess,
  * out: vector potential) and B (in: boundary normal component, out: curl A + correction) as for
- * ndsm_vector_solve - the same bits on the same input.  fp64 only (get_iopt_prec() must be 0);
- * nranks == 1 is ndsm_vector_solve.  Reference: none (shared-memory OpenMP only); pipeline of
+ * ndsm_vector_solve - the same bits on the same input, with ioptc[get_iopt_prec()] != 0 the bits of the
+ * single-GPU mixed-precision mode (the 3-D solves then run ndsm_hip_world_set_precision's scheme where
+ * the slabs allow it).  nranks == 1 is ndsm_vector_solve.  Reference: none (shared-memory OpenMP only); pipeline of
  * ndsm_vector_potential.f90:130-497. */
 int ndsm_hip_world_vector_solve(int rank, int nranks, const int nshape4[4], int ioptc[16], double ropt[16],
                                 const double *x, const double *y, const double *z, double *A_slab, double *B_slab);
@@ -184,7 +185,14 @@ int ndsm_hip_world_slab(void *handle, int ilocal, int *info12);   /* its plan ro
 /* which: 0 = u, 1 = rhs, 2 = residual.  host holds nplanes whole x-y planes starting at GLOBAL
  * plane gz0; the planes that fall into slab ilocal's window (ghosts included) are copied. */
 int ndsm_hip_world_upload(void *handle, int ilocal, int which, const double *host, int gz0, int nplanes);
-int ndsm_hip_world_download(void *handle, int ilocal, int which, double *host /* owned planes */);
+int ndsm_hip_world_download(void *handle, int ilocal, int which, double *host /* Mixed precision on the slabs (BASELINE config[4]): as ndsm_hip_mg_set_precision - 0 fp64, != 0 fp64
+ * residual + fp32 correction V-cycle on level 1 (halo exchange, restriction and prolongation of the
+ * correction in fp32, everything from level 2 down unchanged).  Returns 1 if ndsm_hip_world_solve will
+ * run mixed, 0 if the fp64 path stays (a slab out of the fp32 kernels' reach), < 0 bad arguments.
+ * Same bits as the single-domain mixed mode. */
+int ndsm_hip_world_set_precision(void *world, int mode);
+
+/* owned planes */);
 int ndsm_hip_world_zero_rhs(void *handle);                        /* as ndsm_hip_mg_zero_rhs */
 int ndsm_hip_world_relax(void *handle, int nsweeps);              /* collective */
 int ndsm_hip_world_vcycle(void *handle, int ncycles);             /* collective, asynchronous */

@@ -73,6 +73,7 @@ def load_library(path=None):
     L.ndsm_hip_world_relax.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndsm_hip_world_zero_rhs.argtypes = [ctypes.c_void_p]
     L.ndsm_hip_world_vcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.ndsm_hip_world_set_precision.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.ndsm_hip_world_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, _dp, _ip, _dp, ctypes.c_int]
     if path is None:
         _LIB = L
@@ -283,6 +284,14 @@ class World:
 
     def relax(self, n=1):
         _check(self.L.ndsm_hip_world_relax(self.h, n), "world_relax", self.L)
+
+    def set_precision(self, mode):
+        """0 fp64, != 0 mixed (fp64 residual, fp32 correction V-cycle on the level-1 slabs);
+        returns True if solve() will run in mixed precision"""
+        rc = self.L.ndsm_hip_world_set_precision(self.h, int(mode))
+        if rc < 0:
+            raise NdsmHipError(f"bad precision mode {mode}")
+        return rc == 1
 
     def zero_rhs(self):
         """Declare rhs == 0 on level 1 (Laplace problem): the kernels stop reading it; same bits."""

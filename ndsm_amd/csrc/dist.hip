@@ -114,6 +114,19 @@ int ndsmk_dist_recv(double *p, size_t count, int peer) {
   return 0;
 }
 
+// the same for arrays that are not fp64 (the fp32 correction of the mixed-precision mode)
+int ndsmk_dist_send_bytes(const void *p, size_t nbytes, int peer) {
+  NDSM_CHECK_ARG(g_d.up && peer >= 0 && peer < g_d.size && peer != g_d.rank);
+  NDSM_NCCL(ncclSend(p, nbytes, ncclInt8, peer, g_d.comm, ndsm::stream()));
+  return 0;
+}
+
+int ndsmk_dist_recv_bytes(void *p, size_t nbytes, int peer) {
+  NDSM_CHECK_ARG(g_d.up && peer >= 0 && peer < g_d.size && peer != g_d.rank);
+  NDSM_NCCL(ncclRecv(p, nbytes, ncclInt8, peer, g_d.comm, ndsm::stream()));
+  return 0;
+}
+
 // blocking: h_ms[0] <- max over ranks, h_ms[1] <- sum over ranks
 int ndsmk_dist_allreduce_max_sum(double *h_ms) {
   NDSM_CHECK_ARG(g_d.up);

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(NT) void update_residual_k(const double *__restrict
     const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
     const size_t sz = (size_t)nx * (size_t)ny;
     const int x0 = tx * TXI - 2, y0 = ty * TYI - 1;
-    const int zs = cz * pl.zc, ze = min(zs + pl.zc, nz);
+    const int zs = g.zown0 + cz * pl.zc, ze = min(zs + pl.zc, g.zown1);   // owned planes (z-slab: ghosts either side)
 
     const int lj = tid / NPX, li = 2 * (tid - lj * NPX);
     const int i = x0 + li, j = y0 + lj;
@@ -227,7 +227,9 @@ extern "C" int ndsmk_update_residual_f32(const ndsmk_grid *gp, const double *u, 
   NDSM_REQUIRE_READY();
   const ndsmk_grid g = *gp;
   NDSM_CHECK_ARG(g.ndim == 3 && (g.n[0] & 1) == 0 && g.n[0] >= 4 && g.n[1] >= 2 && g.n[2] >= 2);
-  NDSM_CHECK_ARG(g.zown0 == 0 && g.zown1 == g.n[2]);  // single-domain levels only
+  // z-slabs: owned planes only; the caller keeps one ghost plane of u and e per neighbour current
+  NDSM_CHECK_ARG(g.zown0 >= 0 && g.zown1 <= g.n[2] && g.zown1 > g.zown0);
+  const int nzo = g.zown1 - g.zown0;
   NDSM_CHECK_ARG(u && r && (!e || (unew && ezero && unew != u && ezero != e)));
   constexpr int TXI = kTX - 4, TYI = kTY - 2;
   UPlan pl;
@@ -237,10 +239,10 @@ extern "C" int ndsmk_update_residual_f32(const ndsmk_grid *gp, const double *u, 
   // ~3 workgroups per CU resident (LDS 31 KB, 1024 threads -> 2): chunks of >= 16 planes
   int nzc = (2 * ndsm::cu_count() * 4 + tiles - 1) / tiles;
   if (nzc < 1) nzc = 1;
-  int zc = (g.n[2] + nzc - 1) / nzc;
-  if (zc < 16) zc = 16 < g.n[2] ? 16 : g.n[2];
+  int zc = (nzo + nzc - 1) / nzc;
+  if (zc < 16) zc = 16 < nzo ? 16 : nzo;
   pl.zc = zc;
-  pl.nzc = (g.n[2] + zc - 1) / zc;
+  pl.nzc = (nzo + zc - 1) / zc;
   pl.nwork = tiles * pl.nzc;
   const int nblk = ((pl.nwork + 7) / 8) * 8;
   if ((size_t)nblk > g_m.cap) {

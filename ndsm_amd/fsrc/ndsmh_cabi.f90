@@ -715,6 +715,20 @@ contains
     rc = world_relax(w, int(nsweeps))
   end function
 
+  ! mode as ndsm_hip_mg_set_precision (0 fp64; /= 0 mixed: fp64 residual, fp32 correction V-cycle on the
+  ! level-1 slabs).  Returns 1 if world_solve will run mixed, 0 if the fp64 path stays (a slab out of the
+  ! fp32 kernels' reach: odd nx, < 64 x 16 points per plane), < 0 on a bad handle.
+  function ndsm_hip_world_set_precision(handle, mode) bind(c, name="ndsm_hip_world_set_precision") result(on)
+    type(c_ptr), value :: handle
+    integer(c_int), value :: mode
+    integer(c_int) :: on
+    type(mg_world), pointer :: w
+    on = -1
+    if (.not. c_associated(handle) .or. mode < 0 .or. mode > 2) return
+    call c_f_pointer(handle, w)
+    on = merge(1_c_int, 0_c_int, world_set_precision(w, int(mode)))
+  end function
+
   function ndsm_hip_world_zero_rhs(handle) bind(c, name="ndsm_hip_world_zero_rhs") result(rc)
     type(c_ptr), value :: handle
     integer(c_int) :: rc

@@ -29,6 +29,7 @@ module ndsmh_mg
   public :: mg_set_u, mg_set_rhs, mg_get_u, mg_zero_rhs, mg_level_ptr, mg_op, mg_read_info
   public :: mg_mark_rhs_set
   public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
+  public :: mg_slab_restrict_f32, mg_slab_prolong_f32, mg_mixed_slab_ok, rhs_of
   public :: MG_BUF_U, MG_BUF_RHS, MG_BUF_R
   public :: MG_OP_RELAX_LAST
   public :: MG_OP_RELAX, MG_OP_RESIDUAL, MG_OP_RESTRICT, MG_OP_PROLONG, MG_OP_EXACT, MG_OP_RELAX_COLOR, &
@@ -638,6 +639,59 @@ contains
     else
       rc = ndsmk_prolong_add(s%xf(1)%x, s%cbuf, s%dl(1)%u)
     end if
+  end function
+
+  ! the same two with the fine side in fp32 (mixed-precision mode on z-slabs, ndsmh_world): r32 = the
+  ! e-equation's residual of this slab, e = its correction
+  function mg_slab_restrict_f32(s, r32, dst, dst_k0) result(rc)
+    type(mg_solver), intent(inout) :: s
+    type(c_ptr), intent(in) :: r32
+    type(c_ptr), intent(in), optional :: dst
+    integer, intent(in), optional :: dst_k0
+    integer(c_int) :: rc
+    type(ndsmk_xfer) :: x
+    rc = 0
+    if (s%sl%ck1 <= s%sl%ck0) return
+    x = s%xf(1)%x
+    x%c_cnt = s%sl%ck1 - s%sl%ck0
+    if (present(dst)) then
+      x%c_k0 = dst_k0
+      x%c_beg = s%sl%ck0 - dst_k0
+      rc = ndsmk_restrict_f32(x, r32, dst, c_null_ptr)
+    else
+      x%c_k0 = s%sl%cb0
+      x%c_beg = s%sl%ck0 - s%sl%cb0
+      rc = ndsmk_restrict_f32(x, r32, s%cbuf, c_null_ptr)
+    end if
+  end function
+
+  function mg_slab_prolong_f32(s, e, src, src_k0) result(rc)
+    type(mg_solver), intent(inout) :: s
+    type(c_ptr), intent(in) :: e
+    type(c_ptr), intent(in), optional :: src
+    integer, intent(in), optional :: src_k0
+    integer(c_int) :: rc
+    type(ndsmk_xfer) :: x
+    if (present(src)) then
+      x = s%xf(1)%x
+      x%c_k0 = src_k0
+      rc = ndsmk_prolong_add_f32(x, src, e)
+    else
+      rc = ndsmk_prolong_add_f32(s%xf(1)%x, s%cbuf, e)
+    end if
+  end function
+
+  ! can this z-slab of level 1 run the fp32 kernels? (same conditions as mg_mixed_applies, on the slab)
+  function mg_mixed_slab_ok(s) result(ok)
+    type(mg_solver), intent(in) :: s
+    logical :: ok
+    ok = .false.
+    if (s%ndim /= 3 .or. .not. s%slab .or. s%ms < 1) return
+    if (s%lev(1)%g%all_neumann /= 0) return
+    if (mod(s%lev(1)%n(1), 2) /= 0 .or. s%lev(1)%n(1) < 64 .or. s%lev(1)%n(2) < 16) return
+    if (any(s%lev(2)%n(1:3) < 16)) return
+    if (iand(int(s%xf(1)%x%stream_ok), 2) == 0) return
+    ok = .true.
   end function
 
   ! ------------------------------------------------------------------

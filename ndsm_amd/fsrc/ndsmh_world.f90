@@ -39,6 +39,7 @@ module ndsmh_world
   public :: mg_world, world_create, world_destroy, world_vcycle, world_solve, world_relax
   public :: world_upload, world_download, world_plan_only, world_set_params, world_dist_levels
   public :: ndsmk_dist_group_start, ndsmk_dist_group_end, ndsmk_dist_send, ndsmk_dist_recv   ! for ndsmh_wvecpot
+  public :: world_set_precision
 
   interface
     function ndsmk_dist_size() bind(c, name="ndsmk_dist_size") result(n)
@@ -71,6 +72,20 @@ module ndsmh_world
       integer(c_int), value :: peer
       integer(c_int) :: rc
     end function
+    function ndsmk_dist_send_bytes(p, nbytes, peer) bind(c, name="ndsmk_dist_send_bytes") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: p
+      integer(c_size_t), value :: nbytes
+      integer(c_int), value :: peer
+      integer(c_int) :: rc
+    end function
+    function ndsmk_dist_recv_bytes(p, nbytes, peer) bind(c, name="ndsmk_dist_recv_bytes") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: p
+      integer(c_size_t), value :: nbytes
+      integer(c_int), value :: peer
+      integer(c_int) :: rc
+    end function
     function ndsmk_dist_allreduce_max_sum(ms) bind(c, name="ndsmk_dist_allreduce_max_sum") result(rc)
       import :: c_double, c_int
       real(c_double), intent(inout) :: ms(2)
@@ -96,6 +111,13 @@ module ndsmh_world
     ! traffic to and from rank 0 moves one level down, where it is 8x smaller.
     type(mg_world), pointer :: child => null()
     integer :: level = 1             ! global level index of this world's slabs
+    ! mixed-precision mode (world_solve_mixed): 0 = fp64 throughout; per local slab the fp32 arrays of
+    ! the correction equation - e and its ping-pong partner (in the memory of the fp64 path's ualt),
+    ! the equation's residual rr (in the fp64 residual scratch, dead once restricted) and its
+    ! right-hand side r32 (an array of its own: on rank 0 the scratch also serves level 2)
+    integer :: precision = 0
+    type(c_ptr), allocatable :: e(:), ealt(:), rr32(:), r32(:)
+    integer :: eghost = 0            ! ghost planes of e per side that match the neighbours
   end type
 
 contains
@@ -249,10 +271,17 @@ contains
   recursive subroutine world_destroy(w)
     type(mg_world), intent(inout) :: w
     integer :: i
+    integer(c_int) :: rcf
     if (associated(w%child)) then
       call world_destroy(w%child)
       deallocate (w%child)
       w%child => null()
+    end if
+    if (allocated(w%r32)) then
+      do i = 1, size(w%r32)
+        if (c_associated(w%r32(i))) rcf = ndsmk_free(w%r32(i))
+      end do
+      deallocate (w%r32)
     end if
     if (allocated(w%loc)) then
       do i = 1, size(w%loc)
@@ -625,6 +654,10 @@ contains
     integer(c_size_t) :: off, nb
     integer(ik) :: nown
 
+    if (w%precision /= 0) then
+      rc = world_solve_mixed(w, vc_tol, nmax, du_last, ncycles, ierr, hist)
+      return
+    end if
     du = huge(du); ncycles = 0; ierr = 1
     do i = 1, w%nlocal
       rc = ndsmk_d2d(w%loc(i)%prev, w%loc(i)%dl(1)%u, int(w%loc(i)%npts1, c_size_t) * R8); if (rc /= 0) return
@@ -642,6 +675,250 @@ contains
           tot(1) = max(tot(1), met(1)); tot(2) = tot(2) + met(2)
         end associate
       end do
+      if (w%rccl) then
+        rc = ndsmk_dist_allreduce_max_sum(tot); if (rc /= 0) return
+      end if
+      if (w%loc(1)%use_max) then
+        du = tot(1)
+      else
+        du = tot(2) / (real(w%nzg, wp) * real(w%loc(1)%plane1, wp))
+      end if
+      ncycles = it
+      if (present(hist)) then
+        if (it <= size(hist)) hist(it) = du
+      end if
+      if (du < vc_tol) then
+        ierr = 0
+        exit
+      end if
+    end do
+    du_last = du
+    rc = 0
+  end function
+
+  ! ------------------------------------------------------------------
+  ! Mixed precision on z-slabs (BASELINE config[4]): the iterative refinement of mg_solve_mixed -
+  ! fp64 residual, ONE V-cycle on the correction e with level 1 in fp32, u += e in fp64 - with
+  ! level 1 cut into slabs.  mode /= 0 asks for it; returns whether world_solve will run it
+  ! (every slab must be in reach of the fp32 kernels: nx even, >= 64 x 16 per plane, streamed
+  ! restriction; otherwise the fp64 path stays).  Same arithmetic as the single-domain mode: the
+  ! same launches, cut along z - bit-identical to it (tests).
+  ! ------------------------------------------------------------------
+  function world_set_precision(w, mode) result(on)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: mode
+    logical :: on
+    integer :: i
+    integer(c_int) :: rc
+    integer(c_size_t) :: half
+    on = .false.
+    w%precision = 0
+    if (mode == 0 .or. w%nranks < 2 .or. w%plan(0)%g < 4) return
+    do i = 1, w%nlocal
+      if (.not. mg_mixed_slab_ok(w%loc(i))) return
+    end do
+    if (.not. allocated(w%e)) then
+      allocate (w%e(w%nlocal), w%ealt(w%nlocal), w%rr32(w%nlocal), w%r32(w%nlocal))
+      w%r32 = c_null_ptr
+      do i = 1, w%nlocal
+        half = int(w%loc(i)%npts1, c_size_t) * 4_c_size_t
+        rc = ndsmk_alloc(w%r32(i), half); if (rc /= 0) return
+      end do
+    end if
+    w%precision = mode
+    on = .true.
+  end function
+
+  ! ghost exchange of a level-1 sized fp32 array (p(i): its base on local slab i)
+  function exchange_f32(w, p, depth) result(rc)
+    type(mg_world), intent(inout) :: w
+    type(c_ptr), intent(in) :: p(:)
+    integer, intent(in) :: depth
+    integer(c_int) :: rc
+    integer :: i, r, g, nown
+    integer(c_size_t) :: pl, nb
+    integer(c_size_t), parameter :: R4 = 4_c_size_t
+    rc = 0
+    if (w%nranks == 1) return
+    if (w%rccl) then
+      rc = ndsmk_dist_group_start(); if (rc /= 0) return
+    end if
+    do i = 1, w%nlocal
+      associate (s => w%loc(i))
+        r = s%sl%rank; g = s%sl%g; nown = s%sl%z1 - s%sl%z0
+        pl = int(s%plane1, c_size_t) * R4
+        nb = int(depth, c_size_t) * pl
+        if (r < w%nranks - 1) then
+          if (w%rccl) then
+            rc = ndsmk_dist_send_bytes(dptr_offset(p(i), int(g + nown - depth, c_size_t) * pl), nb, int(r + 1, c_int))
+            if (rc /= 0) return
+            rc = ndsmk_dist_recv_bytes(dptr_offset(p(i), int(g + nown, c_size_t) * pl), nb, int(r + 1, c_int))
+            if (rc /= 0) return
+          else
+            rc = ndsmk_d2d(dptr_offset(p(i + 1), int(w%loc(i + 1)%sl%g - depth, c_size_t) * pl), &
+                           dptr_offset(p(i), int(g + nown - depth, c_size_t) * pl), nb)
+            if (rc /= 0) return
+            rc = ndsmk_d2d(dptr_offset(p(i), int(g + nown, c_size_t) * pl), &
+                           dptr_offset(p(i + 1), int(w%loc(i + 1)%sl%g, c_size_t) * pl), nb)
+            if (rc /= 0) return
+          end if
+        end if
+        if (r > 0 .and. w%rccl) then
+          rc = ndsmk_dist_send_bytes(dptr_offset(p(i), int(g, c_size_t) * pl), nb, int(r - 1, c_int))
+          if (rc /= 0) return
+          rc = ndsmk_dist_recv_bytes(dptr_offset(p(i), int(g - depth, c_size_t) * pl), nb, int(r - 1, c_int))
+          if (rc /= 0) return
+        end if
+      end associate
+    end do
+    if (w%rccl) rc = ndsmk_dist_group_end()
+  end function
+
+  function need_e_ghosts(w, depth) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: depth
+    integer(c_int) :: rc
+    rc = 0
+    if (w%eghost >= depth) return
+    rc = exchange_f32(w, w%e, depth); if (rc /= 0) return
+    w%eghost = depth
+  end function
+
+  ! nsweeps fp32 sweeps of L e = r32 on every local slab, passes of two with a depth-4 exchange as in
+  ! world_relax; with_res: the e-equation's residual (rr32) rides on the last sweep
+  function world_relax_f32(w, nsweeps, with_res) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: nsweeps
+    logical, intent(in) :: with_res
+    integer(c_int) :: rc
+    integer :: left, n, i
+    integer(c_int) :: in_alt
+    type(c_ptr) :: rout, tmp
+    rc = 0
+    left = nsweeps
+    do while (left > 0)
+      n = 1
+      if (left >= 2 .and. .not. (with_res .and. left == 2)) n = 2
+      rout = c_null_ptr
+      if (with_res .and. left == 1) then
+        rc = need_e_ghosts(w, 3); if (rc /= 0) return
+      else
+        rc = need_e_ghosts(w, 2 * n); if (rc /= 0) return
+      end if
+      do i = 1, w%nlocal
+        if (with_res .and. left == 1) rout = w%rr32(i)
+        rc = ndsmk_relax_f32(w%loc(i)%lev(1)%g, w%e(i), w%ealt(i), w%r32(i), int(n, c_int), 1_c_int, rout, in_alt)
+        if (rc /= 0) return
+        if (in_alt /= 0) then
+          tmp = w%e(i); w%e(i) = w%ealt(i); w%ealt(i) = tmp
+        end if
+      end do
+      w%eghost = 0
+      left = left - n
+    end do
+  end function
+
+  function world_solve_mixed(w, vc_tol, nmax, du_last, ncycles, ierr, hist) result(rc)
+    type(mg_world), intent(inout) :: w
+    real(wp), intent(in) :: vc_tol
+    integer, intent(in) :: nmax
+    real(wp), intent(out) :: du_last
+    integer, intent(out) :: ncycles, ierr
+    real(wp), intent(inout), optional :: hist(:)
+    integer(c_int) :: rc
+    real(wp) :: met(2), tot(2), du
+    integer :: it, i, g
+    integer(c_size_t) :: half, pl4
+    type(c_ptr) :: tmp
+
+    du = huge(du); ncycles = 0; ierr = 1
+    du_last = du
+    g = w%plan(0)%g
+    do i = 1, w%nlocal
+      associate (s => w%loc(i))
+        half = int(s%npts1, c_size_t) * 4_c_size_t
+        w%e(i) = s%dl(1)%ualt; w%ealt(i) = dptr_offset(s%dl(1)%ualt, half)
+        w%rr32(i) = s%r
+        rc = ndsmk_fill0(s%dl(1)%ualt, 2_c_size_t * half); if (rc /= 0) return     ! e = 0, ghosts included
+      end associate
+    end do
+    w%eghost = g
+    ! r32 = rhs - L u (fp64 arithmetic): one ghost plane of u, then the ghosts of r32
+    rc = need_ghosts(w, 1); if (rc /= 0) return
+    do i = 1, w%nlocal
+      associate (s => w%loc(i))
+        rc = ndsmk_update_residual_f32(s%lev(1)%g, s%dl(1)%u, c_null_ptr, rhs_of(s, 1), c_null_ptr, c_null_ptr, &
+                                       w%r32(i), met)
+        if (rc /= 0) return
+      end associate
+    end do
+    rc = exchange_f32(w, w%r32, g); if (rc /= 0) return
+
+    do it = 1, nmax
+      ! ---- one V-cycle on the correction (world_vcycle with level 1 in fp32) ----
+      rc = world_relax_f32(w, w%loc(1)%ms, .true.); if (rc /= 0) return
+      rc = exchange_f32(w, w%rr32, g); if (rc /= 0) return
+      if (associated(w%child)) then
+        associate (c => w%child)
+          do i = 1, w%nlocal
+            rc = mg_slab_restrict_f32(w%loc(i), w%rr32(i), c%loc(i)%dl(1)%rhs, c%loc(i)%sl%k0); if (rc /= 0) return
+            rc = ndsmk_fill0(c%loc(i)%dl(1)%u, int(c%loc(i)%npts1, c_size_t) * R8); if (rc /= 0) return
+            call mg_mark_rhs_set(c%loc(i))
+            c%loc(i)%ms = w%loc(i)%ms
+          end do
+          rc = exchange(c, MG_BUF_RHS, c%plan(0)%g); if (rc /= 0) return
+          c%ghost_depth = c%plan(0)%g
+          rc = world_vcycle(c); if (rc /= 0) return
+          rc = world_relax(c, c%loc(1)%ms); if (rc /= 0) return
+          rc = need_ghosts(c, c%plan(0)%g); if (rc /= 0) return
+          do i = 1, w%nlocal
+            rc = mg_slab_prolong_f32(w%loc(i), w%e(i), c%loc(i)%dl(1)%u, c%loc(i)%sl%k0); if (rc /= 0) return
+          end do
+        end associate
+      else
+        do i = 1, w%nlocal
+          rc = mg_slab_restrict_f32(w%loc(i), w%rr32(i)); if (rc /= 0) return
+        end do
+        rc = gather_coarse(w); if (rc /= 0) return
+        do i = 1, w%nlocal
+          if (w%loc(i)%sl%rank /= 0) cycle
+          if (w%loc(i)%ngrids == 2) then
+            rc = mg_op(w%loc(i), MG_OP_EXACT, 2, 1); if (rc /= 0) return
+          else
+            rc = mg_vcycle_from(w%loc(i), 2); if (rc /= 0) return
+          end if
+          rc = mg_op(w%loc(i), MG_OP_RELAX, 2, w%loc(i)%ms); if (rc /= 0) return
+        end do
+        rc = scatter_coarse(w); if (rc /= 0) return
+        do i = 1, w%nlocal
+          rc = mg_slab_prolong_f32(w%loc(i), w%e(i)); if (rc /= 0) return
+        end do
+      end if
+      w%eghost = 0
+      rc = world_relax_f32(w, w%loc(1)%ms, .false.); if (rc /= 0) return
+
+      ! ---- u' = u + e ; e' = 0 ; next residual ; max|e| ----
+      rc = need_e_ghosts(w, 1); if (rc /= 0) return
+      rc = need_ghosts(w, 1); if (rc /= 0) return
+      tot = 0
+      do i = 1, w%nlocal
+        associate (s => w%loc(i))
+          ! the kernel zeroes the owned planes of the next e; its ghost planes here
+          pl4 = int(s%plane1, c_size_t) * 4_c_size_t
+          rc = ndsmk_fill0(w%ealt(i), int(s%sl%g, c_size_t) * pl4); if (rc /= 0) return
+          rc = ndsmk_fill0(dptr_offset(w%ealt(i), int(s%sl%g + s%sl%z1 - s%sl%z0, c_size_t) * pl4), &
+                           int(s%sl%nloc - s%sl%g - (s%sl%z1 - s%sl%z0), c_size_t) * pl4)
+          if (rc /= 0) return
+          rc = ndsmk_update_residual_f32(s%lev(1)%g, s%dl(1)%u, s%prev, rhs_of(s, 1), w%e(i), w%ealt(i), w%r32(i), met)
+          if (rc /= 0) return
+          tmp = s%dl(1)%u; s%dl(1)%u = s%prev; s%prev = tmp
+          tmp = w%e(i); w%e(i) = w%ealt(i); w%ealt(i) = tmp
+          tot(1) = max(tot(1), met(1)); tot(2) = tot(2) + met(2)
+        end associate
+      end do
+      w%ghost_depth = 0                 ! u' was written on owned planes only
+      w%eghost = g                      ! e = 0 everywhere
+      rc = exchange_f32(w, w%r32, g); if (rc /= 0) return
       if (w%rccl) then
         rc = ndsmk_dist_allreduce_max_sum(tot); if (rc /= 0) return
       end if

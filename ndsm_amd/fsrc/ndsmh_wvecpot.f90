@@ -16,8 +16,8 @@
 !      stays in HBM
 !   4. one ghost plane of A per neighbour, flux-balance fields and curl on the slab (post.hip's
 !      slab form), one download of the rank's A and B planes
-! Same bits as the single-GPU call on identical input (tests/test_gpu_multirank.py).
-! fp64 only: the mixed-precision option is a single-domain mode.
+! Same bits as the single-GPU call on identical input (tests/test_gpu_multirank.py), in fp64 and with
+! the mixed-precision option (world_set_precision).
 module ndsmh_wvecpot
 
   use, intrinsic :: iso_c_binding
@@ -71,7 +71,6 @@ contains
     end if
     rc = NDSMK_EARG
     if (nranks < 2 .or. rank < 0 .or. rank >= nranks) return
-    if (iopt(IOPT_PREC) /= 0) return                 ! mixed precision: single domain only
     rc = world_plan_only(n3, qx, qy, qz, ngr, nranks, plan)
     if (rc /= 0) return
     z0 = plan(rank)%z0; z1 = plan(rank)%z1; nzl = z1 - z0
@@ -220,6 +219,9 @@ contains
       if (rc /= 0) goto 900
       call world_set_params(w, merge(5, int(iopt(IOPT_MS)), c == 3), ropt(ROPT_CTOL), iopt(IOPT_DUMAX) == 1, &
                             int(iopt(IOPT_NMAXEX)))          ! Q2
+      if (iopt(IOPT_PREC) /= 0) then                       ! fp32 correction cycle where the slabs allow it
+        if (.not. world_set_precision(w, int(iopt(IOPT_PREC)))) continue
+      end if
       rc = mg_zero_rhs(w%loc(1)); if (rc /= 0) goto 900     ! :640-641 rhs = 0
       rc = world_upload(w, 1, MG_BUF_U, c_loc(comp), z0, nzl); if (rc /= 0) goto 900
       rc = world_solve(w, ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du_last, ncyc, ierr3d); if (rc /= 0) goto 900

@@ -80,7 +80,7 @@ def vector_potential(x, y, z, b, niterex_max=10000, ncycles_max=1024, ex_tol=1e-
     ioptc[slots["debug"]] = lib.get_iopt_true() if debug else lib.get_iopt_false()
     ioptc[slots["dumax"]] = lib.get_iopt_false() if mean else lib.get_iopt_true()
     if mixed_precision:
-        ioptc[lib.get_iopt_prec()] = 1
+        ioptc[lib.get_iopt_prec()] = int(mixed_precision)    # True/1: where level 1 is large; 2: wherever the fp32 kernels apply
 
     apot = np.zeros(b.size, dtype=np.float64)
     bflat = b.flatten()
@@ -89,7 +89,7 @@ def vector_potential(x, y, z, b, niterex_max=10000, ncycles_max=1024, ex_tol=1e-
 
 
 def vector_potential_slab(x, y, z, b_slab, rank, nranks, niterex_max=10000, ncycles_max=1024, ex_tol=1e-13, vc_tol=1e-10,
-                          ms=5, mean=False, debug=False, a_init=None, lib=None):
+                          ms=5, mean=False, debug=False, a_init=None, lib=None, mixed_precision=False):
     """`vector_potential` on a z-slab decomposition (additive; BASELINE config[4]): one process per
     GPU, called collectively by every rank of the communicator set up with `_lib.dist_init`.
 
@@ -113,6 +113,8 @@ def vector_potential_slab(x, y, z, b_slab, rank, nranks, niterex_max=10000, ncyc
     ropt[L.get_ropt_ctol()] = ex_tol
     ioptc[L.get_iopt_debug()] = L.get_iopt_true() if debug else L.get_iopt_false()
     ioptc[L.get_iopt_dumax()] = L.get_iopt_false() if mean else L.get_iopt_true()
+    if mixed_precision:
+        ioptc[L.get_iopt_prec()] = int(mixed_precision)
     apot = np.zeros(b_slab.size) if a_init is None else np.ascontiguousarray(a_init, dtype=np.float64).flatten()
     assert apot.size == b_slab.size
     bflat = b_slab.flatten()

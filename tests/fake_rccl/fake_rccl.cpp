@@ -1,8 +1,8 @@
 // TEST DOUBLE - not part of the product.  A stand-in for the handful of RCCL
 // entry points libndsm_hip calls, for rehearsing the multi-rank code path on a
 // box with ONE GPU (RCCL itself refuses two ranks on one device: "Duplicate GPU
-// detected").  LD_PRELOADed into each rank's process it moves the data through
-// a POSIX shared-memory file instead of xGMI, with RCCL's matching rules kept
+// detected").  Linked under the product's own objects (libndsm_hip_fake.so,
+// see the Makefile) it moves the data through a POSIX shared-memory file instead of xGMI, with RCCL's matching rules kept
 // strict so that the mistakes a real run would hang or corrupt on fail here:
 //   * point-to-point operations between a pair of ranks match in issue order
 //     and must agree on the element count (checked);
@@ -11,7 +11,7 @@
 //   * the operations of one ncclGroupStart/End progress together;
 //   * every wait has a deadline and returns ncclInternalError instead of hanging.
 // Operations run on the host: the stream is drained, the payload copied D2H /
-// H2D with hipMemcpy.  Only ncclDouble is supported (all the library uses).
+// H2D with hipMemcpy.  ncclDouble and ncclInt8 payloads (all the library uses).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -52,7 +52,7 @@ struct Shared {
 struct Op {
   bool send;
   void *p;
-  size_t count;
+  size_t count;   // BYTES
   int peer;
   hipStream_t s;
   int slot = -1;        // ring position taken by this op
@@ -133,8 +133,8 @@ ncclResult_t run_ops(Comm *c, std::vector<Op> &ops) {
           int k = c->head[o.peer] % NSLOT;
           SlotHdr &h = c->sh->slot[c->rank][o.peer][k];
           if (h.full.load(std::memory_order_acquire) == 0) {
-            if (o.count * 8 > c->sh->slot_bytes) return complain("message larger than FAKE_RCCL_SLOT_MB");
-            if (hipMemcpy(payload(c, c->rank, o.peer, k), o.p, o.count * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            if (o.count > c->sh->slot_bytes) return complain("message larger than FAKE_RCCL_SLOT_MB");
+            if (hipMemcpy(payload(c, c->rank, o.peer, k), o.p, o.count, hipMemcpyDeviceToHost) != hipSuccess)
               return complain("D2H failed");
             h.count = o.count;
             h.full.store(1, std::memory_order_release);
@@ -151,11 +151,11 @@ ncclResult_t run_ops(Comm *c, std::vector<Op> &ops) {
         SlotHdr &h = c->sh->slot[o.peer][c->rank][k];
         if (h.full.load(std::memory_order_acquire) == 1) {
           if (h.count != o.count) {
-            fprintf(stderr, "fake_rccl[rank %d]: recv of %zu elements from rank %d matched a send of %zu\n",
+            fprintf(stderr, "fake_rccl[rank %d]: recv of %zu bytes from rank %d matched a send of %zu\n",
                     c->rank, o.count, o.peer, h.count);
             return ncclInternalError;
           }
-          if (hipMemcpy(o.p, payload(c, o.peer, c->rank, k), o.count * 8, hipMemcpyHostToDevice) != hipSuccess)
+          if (hipMemcpy(o.p, payload(c, o.peer, c->rank, k), o.count, hipMemcpyHostToDevice) != hipSuccess)
             return complain("H2D failed");
           h.full.store(0, std::memory_order_release);
           o.state = 2; c->tail[o.peer]++; --left; moved = true;
@@ -258,15 +258,17 @@ ncclResult_t ncclGroupEnd() {
   return run_ops(g_comm, ops);
 }
 
+static size_t esize(ncclDataType_t dt) { return dt == ncclDouble ? 8 : (dt == ncclInt8 ? 1 : 0); }
+
 ncclResult_t ncclSend(const void *p, size_t count, ncclDataType_t dt, int peer, ncclComm_t, hipStream_t s) {
-  if (dt != ncclDouble) return complain("only ncclDouble is modelled");
-  Op o{true, const_cast<void *>(p), count, peer, s};
+  if (!esize(dt)) return complain("only ncclDouble and ncclInt8 are modelled");
+  Op o{true, const_cast<void *>(p), count * esize(dt), peer, s};
   return submit(o);
 }
 
 ncclResult_t ncclRecv(void *p, size_t count, ncclDataType_t dt, int peer, ncclComm_t, hipStream_t s) {
-  if (dt != ncclDouble) return complain("only ncclDouble is modelled");
-  Op o{false, p, count, peer, s};
+  if (!esize(dt)) return complain("only ncclDouble and ncclInt8 are modelled");
+  Op o{false, p, count * esize(dt), peer, s};
   return submit(o);
 }
 

@@ -44,6 +44,8 @@ def main():
         u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
         W = _lib.World(ns, mesh, c["bcs"], world, rank, lib=L)
         assert W.nlocal == 1
+        if c.get("precision"):
+            assert W.set_precision(c["precision"])
         sl = W.slabs[0]
         res = {"z0": sl["z0"], "z1": sl["z1"], "dist_levels": W.dist_levels}
 

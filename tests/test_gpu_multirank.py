@@ -65,6 +65,8 @@ def _check_against_single(hip, out, world, cases):
         shp = tuple(ns[::-1])
         u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
         S = hip.MGSolver(ns, mesh, c["bcs"])
+        if c.get("precision"):
+            assert S.set_precision(c["precision"])
         infos = [json.load(open(os.path.join(out, f"c{ci}_r{r}.json"))) for r in range(world)]
         assert infos[0]["z0"] == 0 and infos[-1]["z1"] == ns[2]
         assert all(infos[r]["z1"] == infos[r + 1]["z0"] for r in range(world - 1))
@@ -115,6 +117,20 @@ def test_ranks_on_one_gpu_distributed_levels(hip, tmp_path, world, ns, levels):
 
 
 @pytest.mark.parametrize("world", (2, 3))
+def test_ranks_on_one_gpu_mixed_precision(hip, tmp_path, world):
+    """mixed precision on the slabs (fp64 residual, fp32 correction V-cycle with fp32 halo exchange,
+    restriction and prolongation) against the single-domain mixed mode: sweeps and V-cycles stay fp64
+    operations; the solve - du history, cycle count, solution bits - must agree exactly"""
+    cases = [
+        {"ns": [128, 64, 96], "bcs": "NDDNDD", "precision": 2, "laplace": True},
+        {"ns": [64, 80, 120], "bcs": "DDNDDN", "precision": 2},
+        {"ns": [128, 64, 192], "bcs": "DNDDND", "precision": 2, "levels": 2, "env": {"NDSM_HIP_DIST_LEVELS": "2"}},
+    ]
+    out = _run_world(tmp_path, world, cases)
+    _check_against_single(hip, out, world, cases)
+
+
+@pytest.mark.parametrize("world", (2, 3))
 def test_distributed_vector_potential_bitwise(hip, tmp_path, world):
     """ndsm_hip_world_vector_solve (ndsmh_wvecpot: faces gathered on rank 0, 3-D solves on z-slab worlds,
     flux balance + curl on the slabs) against ndsm_vector_solve on the whole field: every rank's planes
@@ -126,6 +142,7 @@ def test_distributed_vector_potential_bitwise(hip, tmp_path, world):
         {"ns": [40, 36, 48]},
         {"ns": [33, 30, 45], "noise": 5, "guess": 6, "kw": {"ms": 3, "mean": True}},
         {"ns": [64, 48, 96], "noise": 7, "kw": {"ncycles_max": 3}},
+        {"ns": [64, 64, 96], "kw": {"mixed_precision": 2}},
     ]
     out = _run_world(tmp_path, world, cases, worker="multirank_vecpot_worker.py")
     for ci, c in enumerate(cases):

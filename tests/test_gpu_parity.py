@@ -779,6 +779,52 @@ def test_random_shapes_fused_launches(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ns,nranks,levels", (([128, 64, 160], 2, 0), ([64, 64, 256], 4, 2), ([128, 96, 192], 3, 0),
+                                             ([128, 64, 256], 2, 3)), ids=str)
+def test_slab_world_mixed_precision_bitwise(hip, ns, nranks, levels):
+    """mixed precision on z-slabs (ndsm_hip_world_set_precision; BASELINE config[4]): fp64 residual, fp32
+    correction V-cycle with the level-1 halo exchange, restriction and prolongation in fp32 - the
+    single-domain mixed mode cut along z.  Loop-back world vs the single-domain mixed solver: du history,
+    cycle count and solution bits; and the mode really is on (its iterates differ from the fp64 ones)."""
+    if levels:
+        os.environ["NDSM_HIP_DIST_LEVELS"] = str(levels)
+    try:
+        mesh = uniform_mesh(ns)
+        shp = tuple(ns[::-1])
+        u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
+        for bcs, lap in (("NDDNDD", True), ("DDNDDN", False)):
+            S = hip.MGSolver(ns, mesh, bcs)
+            W = hip.World(ns, mesh, bcs, nranks)
+            W64 = hip.World(ns, mesh, bcs, nranks)
+            assert S.set_precision(2) and W.set_precision(2)
+            if levels:
+                assert W.dist_levels == levels
+            S.upload(1, hip.BUF_U, u)
+            for X in (W, W64):
+                X.upload(hip.BUF_U, u)
+            if lap:
+                for X in (S, W, W64):
+                    X.zero_rhs()
+            else:
+                S.upload(1, hip.BUF_RHS, rhs)
+                for X in (W, W64):
+                    X.upload(hip.BUF_RHS, rhs)
+            a = S.solve(vc_tol=1e-9, nmax=6, hist_len=8)
+            b = W.solve(vc_tol=1e-9, nmax=6, hist_len=8)
+            c = W64.solve(vc_tol=1e-9, nmax=6, hist_len=8)
+            assert (a[0], a[2]) == (b[0], b[2]) and list(a[3]) == list(b[3]), (bcs, list(a[3]), list(b[3]))
+            ub = W.download(hip.BUF_U)
+            assert np.array_equal(S.download(1, hip.BUF_U), ub), bcs
+            u64 = W64.download(hip.BUF_U)
+            assert not np.array_equal(ub, u64) and np.abs(ub - u64).max() <= 1e-6 * np.abs(u64).max(), bcs
+            assert list(b[3]) != list(c[3])
+            for X in (S, W, W64):
+                X.close()
+    finally:
+        os.environ.pop("NDSM_HIP_DIST_LEVELS", None)
+
+
+@pytest.mark.gpu
 def test_random_slab_worlds(hip):
     """seeded random shapes, 2..8 slabs, 1..3 distributed levels, exchange overlap on or off, random ms and
     face letters: three solve-loop cycles of the loop-back world return the single-domain solver's du
