@@ -156,6 +156,59 @@ __global__ __launch_bounds__(1024) void rbgs2_small(double *__restrict__ u_g, co
   for (int p = threadIdx.x; p < n; p += blockDim.x) u_g[p] = u[p];
 }
 
+// Mid-size 2-D level (4096 < points <= kMed2D, e.g. the 128^2 level of a 2-D face solve): the same
+// single-workgroup scheme with only u in LDS (up to 152 KB, dynamic) and the right-hand side read
+// from global memory (L2-resident: one 8-byte read per update).  A level of 16384 points otherwise
+// costs ~5 launches per sweep (two colours, two-stage mean, subtraction), i.e. ~50 dispatch
+// latencies per level visit; this is one.
+constexpr int kMed2D = 19456;
+__global__ __launch_bounds__(1024) void rbgs2_medium(double *__restrict__ u_g, const double *__restrict__ rhs_g,
+                                                     ndsmk_grid g, int nsweeps) {
+  extern __shared__ __attribute__((aligned(16))) double u[];  // the whole level
+  __shared__ double red[16];
+  const int nx = g.n[0], ny = g.n[1];
+  const int n = nx * ny;
+  for (int p = threadIdx.x; p < n; p += blockDim.x) u[p] = u_g[p];
+  __syncthreads();
+  const int mx = g.ub[0] - g.lb[0] + 1, my = g.ub[1] - g.lb[1] + 1;
+  const int half = (mx + 1) / 2;
+  const int total = half * my;
+  for (int sw = 0; sw < nsweeps; ++sw) {
+    for (int pass = 0; pass < 2; ++pass) {
+      const int par = (g.first_par + pass) & 1;
+      for (int p = threadIdx.x; p < total; p += blockDim.x) {
+        const int t = p % half, j = g.lb[1] + p / half;
+        const int i0 = g.lb[0] + ((((g.lb[0] + j) & 1) != par) ? 1 : 0);
+        const int i = i0 + 2 * t;
+        if (i > g.ub[0]) continue;
+        const int xl = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i - 1);
+        const int xh = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i + 1);
+        const int yl = (j == 0) ? 1 : (j == ny - 1 ? ny - 2 : j - 1);
+        const int yh = (j == 0) ? 1 : (j == ny - 1 ? ny - 2 : j + 1);
+        const double r = rhs_g ? rhs_g[i + nx * j] : 0.0;
+        double un = 0.0;  // ndsm_poisson.f90:603-617
+        un = un + u[xl + nx * j] * g.w[0] + u[xh + nx * j] * g.w[0];
+        un = un + u[i + nx * yl] * g.w[1] + u[i + nx * yh] * g.w[1];
+        u[i + nx * j] = (un - r) * g.w1;
+      }
+      __syncthreads();
+    }
+    if (g.all_neumann) {
+      double sm = 0.0;
+      for (int p = threadIdx.x; p < n; p += blockDim.x) sm = sm + u[p];
+      for (int o = 32; o > 0; o >>= 1) sm = sm + __shfl_down(sm, o, 64);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sm;
+      __syncthreads();
+      double tot = 0.0;
+      for (int q = 0; q < 16; ++q) tot = tot + red[q];
+      const double mean = tot / (double)n;
+      for (int p = threadIdx.x; p < n; p += blockDim.x) u[p] = u[p] - mean;
+      __syncthreads();
+    }
+  }
+  for (int p = threadIdx.x; p < n; p += blockDim.x) u_g[p] = u[p];
+}
+
 __global__ __launch_bounds__(256) void rbgs2_color(double *__restrict__ u, const double *__restrict__ rhs,
                                                   ndsmk_grid g, int par) {
   const int nx = g.n[0], ny = g.n[1];
@@ -228,6 +281,22 @@ static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double 
       if (int rc = ndsmk_prolong_add(px, uc, bufs[0])) return rc;
     }
     hipLaunchKernelGGL(rbgs2_small, dim3(1), dim3(1024), 0, s, bufs[0], rhs, g, nsweeps);
+    NDSM_LAUNCH_CHECK();
+    return 0;
+  }
+  // mid-size 2-D level: likewise, u in (dynamic) LDS only
+  if (g.ndim == 2 && variant == 0 && npts <= kMed2D && nsweeps > 0) {
+    NDSM_CHECK_ARG(in_place_ok());
+    if (prol_pending) {
+      if (int rc = ndsmk_prolong_add(px, uc, bufs[0])) return rc;
+    }
+    static bool attr = false;
+    if (!attr) {
+      NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rbgs2_medium), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kMed2D * (int)sizeof(double)));
+      attr = true;
+    }
+    hipLaunchKernelGGL(rbgs2_medium, dim3(1), dim3(1024), (size_t)npts * sizeof(double), s, bufs[0], rhs, g, nsweeps);
     NDSM_LAUNCH_CHECK();
     return 0;
   }
