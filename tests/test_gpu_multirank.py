@@ -168,9 +168,13 @@ def test_distributed_vector_potential_bitwise(hip, tmp_path, world):
 def test_bench_two_ranks_rehearsal(hip):
     """the driver's N=2 command line (torch.distributed.run, gloo rendezvous, slab world, self-check,
     ONE JSON line from rank 0), both ranks on this box's GPU over the test double"""
+    import socket
+    with socket.socket() as sk:                      # a port nobody is listening on
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, NDSM_HIP_LIB=_fake(), FAKE_RCCL_TIMEOUT="120", FAKE_RCCL_SLOT_MB="64")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
