@@ -118,6 +118,11 @@ module ndsmh_world
     integer :: precision = 0
     type(c_ptr), allocatable :: e(:), ealt(:), rr32(:), r32(:)
     integer :: eghost = 0            ! ghost planes of e per side that match the neighbours
+    ! world_solve: the iterate a V-cycle starts from must survive the cycle for update_u's
+    ! max|u_new - u_old|.  Set before the cycle; the first smoothing pass (out of place: u -> ualt)
+    ! then hands the untouched input buffer over to `prev` and takes prev's memory as the new
+    ! ping-pong partner - three rotating buffers instead of a copy of the iterate per cycle.
+    logical :: protect = .false.
   end type
 
 contains
@@ -528,6 +533,7 @@ contains
     integer(c_int) :: rc
     integer :: left, n, i, d
     logical :: res, two_ok
+    type(c_ptr) :: tmp
     rc = 0
     res = .false.
     if (present(with_res)) res = with_res
@@ -569,6 +575,12 @@ contains
         do i = 1, w%nlocal
           rc = mg_op(w%loc(i), MG_OP_RELAX_FUSED, 1, n); if (rc /= 0) return
         end do
+      end if
+      if (w%protect) then              ! first pass of a solve-loop cycle: keep its input (see mg_world)
+        do i = 1, w%nlocal
+          tmp = w%loc(i)%dl(1)%ualt; w%loc(i)%dl(1)%ualt = w%loc(i)%prev; w%loc(i)%prev = tmp
+        end do
+        w%protect = .false.
       end if
       w%ghost_depth = 0
       left = left - n
@@ -653,24 +665,31 @@ contains
     integer :: it, i
     integer(c_size_t) :: off, nb
     integer(ik) :: nown
+    logical :: rot
 
     if (w%precision /= 0) then
       rc = world_solve_mixed(w, vc_tol, nmax, du_last, ncycles, ierr, hist)
       return
     end if
     du = huge(du); ncycles = 0; ierr = 1
-    do i = 1, w%nlocal
-      rc = ndsmk_d2d(w%loc(i)%prev, w%loc(i)%dl(1)%u, int(w%loc(i)%npts1, c_size_t) * R8); if (rc /= 0) return
-    end do
+    rot = w%loc(1)%ms >= 1           ! a cycle without sweeps has no out-of-place pass to rotate on
     do it = 1, nmax
+      if (rot) then
+        w%protect = .true.
+      else
+        do i = 1, w%nlocal
+          rc = ndsmk_d2d(w%loc(i)%prev, w%loc(i)%dl(1)%u, int(w%loc(i)%npts1, c_size_t) * R8); if (rc /= 0) return
+        end do
+      end if
       rc = world_vcycle(w); if (rc /= 0) return
+      w%protect = .false.
       tot = 0
       do i = 1, w%nlocal
         associate (s => w%loc(i))
           off = int(s%sl%g, c_size_t) * int(s%plane1, c_size_t) * R8
           nown = int(s%sl%z1 - s%sl%z0, ik) * s%plane1
           nb = int(nown, c_size_t)
-          rc = ndsmk_diff_metrics(dptr_offset(s%dl(1)%u, off), dptr_offset(s%prev, off), nown, 1_c_int, met)
+          rc = ndsmk_diff_metrics(dptr_offset(s%dl(1)%u, off), dptr_offset(s%prev, off), nown, 0_c_int, met)
           if (rc /= 0) return
           tot(1) = max(tot(1), met(1)); tot(2) = tot(2) + met(2)
         end associate
