@@ -438,18 +438,28 @@ extern "C" int ndsmk_fetch_fused_metric(double *h_out2) {
 // One out-of-place fused pass (nsweeps = 1 or 2) over the owned planes [z0, z1) of a z-slab only:
 // the pieces of a pass whose halo exchange overlaps its interior (ndsmh_world).  u is read
 // (z0 - 2 nsweeps .. z1 + 2 nsweeps must be valid planes), uout written on [z0, z1).
+// px != NULL: u + P uc is formed while the planes are loaded (the launch that starts the
+// post-smoothing; uc holds coarse planes [px->c_k0, px->c_k0 + px->c_cnt), which must cover the
+// brackets of the window's planes AND of the ghost planes the launch reads).  Returns NDSMK_EARG
+// if that launch does not exist for this level (general rhs, one sweep): the caller then
+// interpolates with the stand-alone kernel first.
 extern "C" int ndsmk_fused_window(const ndsmk_grid *gp, const double *u, double *uout, const double *rhs, int nsweeps,
-                                  int z0, int z1) {
+                                  int z0, int z1, const ndsmk_xfer *px, const double *uc) {
   NDSM_REQUIRE_READY();
   ndsmk_grid g = *gp;
   NDSM_CHECK_ARG(g.ndim == 3 && (nsweeps == 1 || nsweeps == 2) && z0 >= g.zown0 && z1 <= g.zown1 && z0 < z1);
+  NDSM_CHECK_ARG(!px || uc);
   g.zown0 = z0;
   g.zown1 = z1;
   int ndone = 0;
-  int rc = ndsm::launch_rbgs3_fused(g, u, uout, rhs, nsweeps, true, &ndone, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                    nullptr);
+  int rc = ndsm::launch_rbgs3_fused(g, u, uout, rhs, nsweeps, true, &ndone, nullptr, nullptr, nullptr, nullptr, px, uc);
   if (rc) return rc;
   if (ndone != nsweeps)
     return ndsm::fail(NDSMK_EARG, "fused smoother: this window / sweep count is not covered", __FILE__, __LINE__);
   return 0;
+}
+
+// can ndsmk_fused_window(..., px, uc) interpolate while it loads? (two sweeps, no right-hand side, fp64)
+extern "C" int ndsmk_fused_prolong_ok(const ndsmk_grid *gp, const double *rhs, int nsweeps) {
+  return (gp->ndim == 3 && !rhs && nsweeps == 2 && !gp->all_neumann) ? 1 : 0;
 }

@@ -57,6 +57,9 @@ struct ProlArgs {
   const int32_t *plo[3];     // per fine index: lower bracket in the coarse axis
   const double *pwl[3], *pwh[3];
   int ncx, ncy, ncz;
+  // z windows (z-slabs; all zero / whole levels otherwise): global index of the fine array's plane 0,
+  // global fine nz, global index of uc's plane 0 and the number of coarse planes uc holds
+  int fk0, nzf, ck0, nczw;
 };
 
 struct FusedPlan {
@@ -426,7 +429,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   // coarse planes kcur, kcur+1 (and, prefetched, kcur+2) of this thread's coarse points
   auto prol_load = [&](int kc, double *dst) {
 #pragma unroll
-    for (int c = 0; c < NCS; ++c) dst[c] = (c_ok[c] && kc < pa.ncz) ? pa.uc[csz * (size_t)kc + c_off[c]] : 0.0;
+    for (int c = 0; c < NCS; ++c)
+      dst[c] = (c_ok[c] && kc >= pa.ck0 && kc < pa.ck0 + pa.nczw) ? pa.uc[csz * (size_t)(kc - pa.ck0) + c_off[c]] : 0.0;
   };
   // advance the rolling coarse planes to the bracket of fine plane kf and park its z-interpolated
   // coarse plane in LDS (the caller puts a barrier between this and prol_corr)
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   int zt_kc = 0;
   double zt_wl = 0.0, zt_wh = 0.0;
   auto prol_ztab = [&](int kf) {
-    const int kq = min(max(kf, 0), nz - 1);
+    const int kq = min(max(kf + pa.fk0, 0), pa.nzf - 1);   // table index = global fine plane
     zt_kc = pa.plo[2][kq];
     zt_wl = pa.pwl[2][kq];
     zt_wh = pa.pwh[2][kq];
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     }
     if (ks + 1 <= ke) NDSM_LOAD_PLANE(u, ks + 1, nxt);
     if (PROL) {  // the two planes loaded here get their correction here
-      kcur = pa.plo[2][ks];
+      kcur = pa.plo[2][min(max(ks + pa.fk0, 0), pa.nzf - 1)];
       prol_ztab(ks);
       prol_load(kcur, c_lo);
       prol_load(kcur + 1, c_hi);
@@ -938,7 +942,7 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   // (*sweeps_done = 0) and the caller interpolates with the stand-alone kernel first.
   if (prol) {
     if constexpr (std::is_same<T, double>::value) {
-      if (!rhs && two && !slab && !(met && max_sweeps == 2) && cfg[0] == 0) {
+      if (!rhs && two && !(met && max_sweeps == 2) && cfg[0] == 0) {
         rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 3, false, ODD>(g, u, uout, rhs, tgt, nullptr, nullptr, prol));
         if (rc) return rc;
         *sweeps_done = 2;
@@ -1019,8 +1023,15 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
     pa.ncx = px->nc[0];
     pa.ncy = px->nc[1];
     pa.ncz = px->nc[2];
-    if (px->f_k0 != 0 || px->c_k0 != 0 || px->nf[0] != g.n[0] || px->nf[1] != g.n[1] || px->nf[2] != g.n[2]) {
-      *sweeps_done = 0;  // windows (z-slabs) are not built into this mode
+    // z windows: the fine array is the slab described by g, uc holds coarse planes [c_k0, c_k0 + c_cnt)
+    // (single domain: c_k0 = 0 and the whole coarse level); the caller guarantees that they cover the
+    // brackets of every fine plane the launch loads (owned planes + ghosts)
+    pa.fk0 = px->f_k0;
+    pa.nzf = px->nf[2];
+    pa.ck0 = px->c_k0;
+    pa.nczw = (px->f_k0 == 0 && px->c_k0 == 0 && px->nf[2] == g.n[2]) ? px->nc[2] : px->c_cnt;
+    if (px->f_k0 != g.k0 || px->nf[0] != g.n[0] || px->nf[1] != g.n[1] || px->nf[2] != g.nzg || pa.nczw < 1) {
+      *sweeps_done = 0;
       return 0;
     }
     if (g.n[0] & 1)

@@ -125,8 +125,10 @@ contains
       plan(r)%g = depth
       plan(r)%nloc = plan(r)%z1 - plan(r)%z0 + 2 * depth
       plan(r)%k0 = plan(r)%z0 - depth
-      plan(r)%pk0 = tz%plo(plan(r)%z0 + 1)
-      plan(r)%pk1 = tz%plo(plan(r)%z1) + 2
+      ! coarse planes the prolongation of this slab reads: the brackets of its owned planes and of its
+      ! ghost planes (the smoother launch that folds the prolongation in corrects those as it loads them)
+      plan(r)%pk0 = tz%plo(max(plan(r)%z0 - depth, 0) + 1)
+      plan(r)%pk1 = tz%plo(min(plan(r)%z1 + depth, nz)) + 2
       plan(r)%cb0 = plan(r)%pk0; plan(r)%cb1 = plan(r)%pk1
       if (plan(r)%ck1 > plan(r)%ck0) then
         plan(r)%cb0 = min(plan(r)%cb0, plan(r)%ck0)

@@ -25,7 +25,7 @@ module ndsmh_mg
   private
 
   public :: mg_solver, mg_create, mg_destroy, mg_vcycle, mg_solve
-  public :: mg_mixed_applies, mg_relax_window, mg_swap_u
+  public :: mg_mixed_applies, mg_relax_window, mg_swap_u, mg_window_prolong_ok
   public :: mg_set_u, mg_set_rhs, mg_get_u, mg_zero_rhs, mg_level_ptr, mg_op, mg_read_info
   public :: mg_mark_rhs_set
   public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
@@ -585,12 +585,35 @@ contains
   ! z-slab level 1, pieces of a pass whose halo exchange overlaps its interior: one fused pass
   ! (n = 1 or 2 sweeps) over the owned LOCAL planes [z0, z1) only, u -> ualt; mg_swap_u when all
   ! pieces of the pass are enqueued
-  function mg_relax_window(s, n, z0, z1) result(rc)
-    type(mg_solver), intent(inout) :: s
+  ! src given: the launch also interpolates the coarse-grid correction while it loads (u + P src;
+  ! src = src_n whole coarse planes starting at global coarse plane src_k0, which must cover the
+  ! brackets of the window's planes and of the ghost planes the launch reads) - only where
+  ! mg_window_prolong_ok says so
+  function mg_relax_window(s, n, z0, z1, src, src_k0, src_n) result(rc)
+    type(mg_solver), intent(inout), target :: s
     integer, intent(in) :: n, z0, z1
+    type(c_ptr), intent(in), optional :: src
+    integer, intent(in), optional :: src_k0, src_n
     integer(c_int) :: rc
-    rc = ndsmk_fused_window(s%lev(1)%g, s%dl(1)%u, s%dl(1)%ualt, rhs_of(s, 1), int(n, c_int), int(z0, c_int), &
-                            int(z1, c_int))
+    type(ndsmk_xfer), target :: x
+    if (present(src)) then
+      x = s%xf(1)%x
+      x%c_k0 = src_k0
+      x%c_cnt = src_n
+      rc = ndsmk_fused_window(s%lev(1)%g, s%dl(1)%u, s%dl(1)%ualt, rhs_of(s, 1), int(n, c_int), int(z0, c_int), &
+                              int(z1, c_int), c_loc(x), src)
+    else
+      rc = ndsmk_fused_window(s%lev(1)%g, s%dl(1)%u, s%dl(1)%ualt, rhs_of(s, 1), int(n, c_int), int(z0, c_int), &
+                              int(z1, c_int), c_null_ptr, c_null_ptr)
+    end if
+  end function
+
+  ! can a pass of n sweeps over this slab fold the prolongation in? (two sweeps, Laplace problem)
+  function mg_window_prolong_ok(s, n) result(ok)
+    type(mg_solver), intent(in) :: s
+    integer, intent(in) :: n
+    logical :: ok
+    ok = ndsmk_fused_prolong_ok(s%lev(1)%g, rhs_of(s, 1), int(n, c_int)) /= 0
   end function
 
   subroutine mg_swap_u(s)

@@ -123,6 +123,10 @@ module ndsmh_world
     ! then hands the untouched input buffer over to `prev` and takes prev's memory as the new
     ! ping-pong partner - three rotating buffers instead of a copy of the iterate per cycle.
     logical :: protect = .false.
+    ! where each local slab interpolates its coarse-grid correction from (set by world_vcycle before the
+    ! post-smoothing): whole coarse planes starting at global coarse plane psk0, psn of them
+    type(c_ptr), allocatable :: psrc(:)
+    integer, allocatable :: psk0(:), psn(:)
   end type
 
 contains
@@ -526,22 +530,42 @@ contains
   ! black of the neighbour plane, black needs that red), so a halo exchange of depth 4 feeds a
   ! two-sweep pass of the temporally blocked kernel: half the messages, half the passes over HBM.
   ! with_res: the residual rides on the last sweep (depth 3: one more plane for its stencil).
-  function world_relax(w, nsweeps, with_res) result(rc)
+  ! prolong: the coarse-grid correction (w%psrc) is still to be added to u.  Where the first pass can
+  ! fold it in (two sweeps, Laplace problem) it reads the UNCORRECTED u - ghosts included, their
+  ! correction is formed locally from the same coarse planes the neighbour uses - and adds P u_c to
+  ! every plane as it loads it; otherwise the stand-alone kernel corrects the owned planes first.
+  function world_relax(w, nsweeps, with_res, prolong) result(rc)
     type(mg_world), intent(inout) :: w
     integer, intent(in) :: nsweeps
-    logical, intent(in), optional :: with_res
+    logical, intent(in), optional :: with_res, prolong
     integer(c_int) :: rc
     integer :: left, n, i, d
-    logical :: res, two_ok
+    logical :: res, two_ok, pro, pend
     type(c_ptr) :: tmp
     rc = 0
     res = .false.
     if (present(with_res)) res = with_res
+    pend = .false.
+    if (present(prolong)) pend = prolong
     two_ok = w%plan(0)%g >= 4
     left = nsweeps
+    if (pend .and. left <= 0) then
+      rc = prolong_alone(w); if (rc /= 0) return
+    end if
     do while (left > 0)
       n = 1
       if (two_ok .and. left >= 2 .and. .not. (res .and. left == 2)) n = 2
+      pro = .false.
+      if (pend) then
+        pro = n == 2 .and. .not. (res .and. left == 1)
+        do i = 1, w%nlocal
+          pro = pro .and. mg_window_prolong_ok(w%loc(i), n)
+        end do
+        if (.not. pro) then
+          rc = prolong_alone(w); if (rc /= 0) return
+        end if
+        pend = .false.
+      end if
       if (res .and. left == 1) then
         rc = need_ghosts(w, 3); if (rc /= 0) return
         do i = 1, w%nlocal
@@ -559,21 +583,26 @@ contains
         if (rc /= 0) return
         do i = 1, w%nlocal
           associate (s => w%loc(i))
-            rc = mg_relax_window(s, n, int(s%lev(1)%g%zown0) + d, int(s%lev(1)%g%zown1) - d); if (rc /= 0) return
+            rc = window_pass(w, i, n, int(s%lev(1)%g%zown0) + d, int(s%lev(1)%g%zown1) - d, pro); if (rc /= 0) return
           end associate
         end do
         rc = ndsmk_stream_fence(1_c_int, 0_c_int); if (rc /= 0) return
         do i = 1, w%nlocal
           associate (s => w%loc(i))
-            rc = mg_relax_window(s, n, int(s%lev(1)%g%zown0), int(s%lev(1)%g%zown0) + d); if (rc /= 0) return
-            rc = mg_relax_window(s, n, int(s%lev(1)%g%zown1) - d, int(s%lev(1)%g%zown1)); if (rc /= 0) return
+            rc = window_pass(w, i, n, int(s%lev(1)%g%zown0), int(s%lev(1)%g%zown0) + d, pro); if (rc /= 0) return
+            rc = window_pass(w, i, n, int(s%lev(1)%g%zown1) - d, int(s%lev(1)%g%zown1), pro); if (rc /= 0) return
             call mg_swap_u(s)
           end associate
         end do
       else
         rc = need_ghosts(w, 2 * n); if (rc /= 0) return
         do i = 1, w%nlocal
-          rc = mg_op(w%loc(i), MG_OP_RELAX_FUSED, 1, n); if (rc /= 0) return
+          if (pro) then
+            rc = window_pass(w, i, n, int(w%loc(i)%lev(1)%g%zown0), int(w%loc(i)%lev(1)%g%zown1), pro); if (rc /= 0) return
+            call mg_swap_u(w%loc(i))
+          else
+            rc = mg_op(w%loc(i), MG_OP_RELAX_FUSED, 1, n); if (rc /= 0) return
+          end if
         end do
       end if
       if (w%protect) then              ! first pass of a solve-loop cycle: keep its input (see mg_world)
@@ -587,10 +616,36 @@ contains
     end do
   end function
 
+  ! one fused pass over local planes [z0, z1) of slab i, u -> ualt, optionally interpolating
+  function window_pass(w, i, n, z0, z1, pro) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: i, n, z0, z1
+    logical, intent(in) :: pro
+    integer(c_int) :: rc
+    if (pro) then
+      rc = mg_relax_window(w%loc(i), n, z0, z1, w%psrc(i), w%psk0(i), w%psn(i))
+    else
+      rc = mg_relax_window(w%loc(i), n, z0, z1)
+    end if
+  end function
+
+  ! u += P u_c on the owned planes with the stand-alone kernel; the ghosts are stale afterwards
+  function prolong_alone(w) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer(c_int) :: rc
+    integer :: i
+    rc = 0
+    do i = 1, w%nlocal
+      rc = mg_slab_prolong(w%loc(i), w%psrc(i), w%psk0(i)); if (rc /= 0) return
+    end do
+    w%ghost_depth = 0
+  end function
+
   recursive function world_vcycle(w) result(rc)
     type(mg_world), intent(inout) :: w
     integer(c_int) :: rc
     integer :: i
+    if (.not. allocated(w%psrc)) allocate (w%psrc(w%nlocal), w%psk0(w%nlocal), w%psn(w%nlocal))
 
     ! ---- level 1, downwards (fine_to_coarse, ndsm_multigrid_core.f90:482-560)
     if (w%loc(1)%ms >= 1 .and. w%plan(0)%g >= 3) then
@@ -622,7 +677,7 @@ contains
         rc = world_relax(c, c%loc(1)%ms); if (rc /= 0) return
         rc = need_ghosts(c, c%plan(0)%g); if (rc /= 0) return
         do i = 1, w%nlocal
-          rc = mg_slab_prolong(w%loc(i), c%loc(i)%dl(1)%u, c%loc(i)%sl%k0); if (rc /= 0) return
+          w%psrc(i) = c%loc(i)%dl(1)%u; w%psk0(i) = c%loc(i)%sl%k0; w%psn(i) = c%loc(i)%sl%nloc
         end do
       end associate
     else
@@ -645,11 +700,11 @@ contains
       ! ---- level 1, upwards (coarse_to_fine, :593-684) --------------------
       rc = scatter_coarse(w); if (rc /= 0) return
       do i = 1, w%nlocal
-        rc = mg_slab_prolong(w%loc(i)); if (rc /= 0) return
+        w%psrc(i) = w%loc(i)%cbuf; w%psk0(i) = w%loc(i)%sl%cb0; w%psn(i) = w%loc(i)%sl%cb1 - w%loc(i)%sl%cb0
       end do
     end if
     w%ghost_depth = 0
-    rc = world_relax(w, w%loc(1)%ms)
+    rc = world_relax(w, w%loc(1)%ms, prolong=.true.)
   end function
 
   ! V-cycles to tolerance; every rank returns the same du history
