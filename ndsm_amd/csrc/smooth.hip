@@ -14,6 +14,7 @@
 #include "common.hpp"
 
 namespace ndsm {
+void fused_metric_accumulate(bool on);
 int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps,
                        bool force, int *sweeps_done, double *rout, int *res_done, const double *prev, int *met_done,
                        const ndsmk_xfer *px, const double *uc);
@@ -443,21 +444,31 @@ extern "C" int ndsmk_fetch_fused_metric(double *h_out2) {
 // brackets of the window's planes AND of the ghost planes the launch reads).  Returns NDSMK_EARG
 // if that launch does not exist for this level (general rhs, one sweep): the caller then
 // interpolates with the stand-alone kernel first.
+// prev != NULL: the launch also evaluates max / sum of |u_new - prev| over the planes it stores
+// (update_u's metric; read back with ndsmk_fetch_fused_metric).  accumulate != 0: added to what the
+// previous such launch left on the device - the windows of one pass, the slabs of one process.
 extern "C" int ndsmk_fused_window(const ndsmk_grid *gp, const double *u, double *uout, const double *rhs, int nsweeps,
-                                  int z0, int z1, const ndsmk_xfer *px, const double *uc) {
+                                  int z0, int z1, const ndsmk_xfer *px, const double *uc, const double *prev,
+                                  int accumulate) {
   NDSM_REQUIRE_READY();
   ndsmk_grid g = *gp;
   NDSM_CHECK_ARG(g.ndim == 3 && (nsweeps == 1 || nsweeps == 2) && z0 >= g.zown0 && z1 <= g.zown1 && z0 < z1);
-  NDSM_CHECK_ARG(!px || uc);
+  NDSM_CHECK_ARG((!px || uc) && !(px && prev));
   g.zown0 = z0;
   g.zown1 = z1;
-  int ndone = 0;
-  int rc = ndsm::launch_rbgs3_fused(g, u, uout, rhs, nsweeps, true, &ndone, nullptr, nullptr, nullptr, nullptr, px, uc);
+  int ndone = 0, met = 0;
+  ndsm::fused_metric_accumulate(accumulate != 0);
+  int rc = ndsm::launch_rbgs3_fused(g, u, uout, rhs, nsweeps, true, &ndone, nullptr, nullptr, prev, prev ? &met : nullptr,
+                                    px, uc);
+  ndsm::fused_metric_accumulate(false);
   if (rc) return rc;
-  if (ndone != nsweeps)
+  if (ndone != nsweeps || (prev && !met))
     return ndsm::fail(NDSMK_EARG, "fused smoother: this window / sweep count is not covered", __FILE__, __LINE__);
   return 0;
 }
+
+// can ndsmk_fused_window(..., prev) evaluate the metric? (fp64 level off the all-Neumann path)
+extern "C" int ndsmk_fused_metric_ok(const ndsmk_grid *gp) { return (gp->ndim == 3 && !gp->all_neumann) ? 1 : 0; }
 
 // can ndsmk_fused_window(..., px, uc) interpolate while it loads? (two sweeps, no right-hand side, fp64)
 extern "C" int ndsmk_fused_prolong_ok(const ndsmk_grid *gp, const double *rhs, int nsweeps) {

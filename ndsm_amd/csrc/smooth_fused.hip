@@ -758,8 +758,9 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 }
 
 // folds the per-workgroup (max, sum) partials of a MET launch in index order
+// (acc: combine with what out2 holds - the launches of one z-slab pass, window by window, slab by slab)
 __global__ __launch_bounds__(256) void fold_metric_k(const double *__restrict__ part, int nblocks,
-                                                     double *__restrict__ out2) {
+                                                     double *__restrict__ out2, int acc) {
   __shared__ double smx[4], ssm[4];
   double mx = 0.0, sm = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
@@ -776,8 +777,10 @@ __global__ __launch_bounds__(256) void fold_metric_k(const double *__restrict__ 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    out2[0] = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
-    out2[1] = ((ssm[0] + ssm[1]) + ssm[2]) + ssm[3];
+    const double m = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
+    const double a = ((ssm[0] + ssm[1]) + ssm[2]) + ssm[3];
+    out2[0] = acc ? fmax(out2[0], m) : m;
+    out2[1] = acc ? out2[1] + a : a;
   }
 }
 
@@ -787,12 +790,18 @@ struct MetScratch {
   size_t cap = 0;
 };
 MetScratch g_met;
+bool g_met_acc = false;  // the next MET launch adds to the folded pair instead of replacing it
 int met_scratch(size_t nblk, double **part, double **out2) {
   if (nblk > g_met.cap) {
-    if (g_met.d) (void)hipFree(g_met.d);
-    g_met.d = nullptr;
-    g_met.cap = 0;
-    NDSM_HIP(hipMalloc((void **)&g_met.d, sizeof(double) * (2 * nblk + 2)));
+    double *nd = nullptr;
+    NDSM_HIP(hipMalloc((void **)&nd, sizeof(double) * (2 * nblk + 2)));
+    if (g_met.d) {  // an accumulation in progress moves with the buffer
+      NDSM_HIP(hipMemcpyAsync(nd + 2 * nblk, g_met.d + 2 * g_met.cap, 2 * sizeof(double), hipMemcpyDeviceToDevice,
+                              ndsm::stream()));
+      NDSM_HIP(hipStreamSynchronize(ndsm::stream()));
+      (void)hipFree(g_met.d);
+    }
+    g_met.d = nd;
     g_met.cap = nblk;
   }
   *part = g_met.d;
@@ -878,7 +887,7 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
                        ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl, pa);
   NDSM_LAUNCH_CHECK();
   if (MODE == 2) {
-    hipLaunchKernelGGL(fold_metric_k, dim3(1), dim3(256), 0, ndsm::stream(), part, nblk, out2);
+    hipLaunchKernelGGL(fold_metric_k, dim3(1), dim3(256), 0, ndsm::stream(), part, nblk, out2, g_met_acc ? 1 : 0);
     NDSM_LAUNCH_CHECK();
   }
   return 0;
@@ -936,7 +945,7 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   const bool two = max_sweeps >= 2 && ghosts >= 4 && cfg[0] != 9 && !(res && max_sweeps == 2);
   // prev != nullptr: the launch that performs the last of the max_sweeps sweeps also evaluates
   // the convergence metric against prev (fp64, single domain; *met_done says it did)
-  const bool met = std::is_same<T, double>::value && prev && met_done && !slab;
+  const bool met = std::is_same<T, double>::value && prev && met_done;
   // prol != nullptr: u + P u_c is to be formed while the planes are loaded (MODE 3).  Built for
   // the two-sweep Laplace launch only; if this call cannot be that launch NOTHING is launched
   // (*sweeps_done = 0) and the caller interpolates with the stand-alone kernel first.
@@ -1050,6 +1059,9 @@ int fetch_fused_metric(double *h_out2) {
   NDSM_HIP(hipStreamSynchronize(stream()));
   return 0;
 }
+
+// the MET launches that follow add their (max, sum) to the pair on the device instead of replacing it
+void fused_metric_accumulate(bool on) { g_met_acc = on; }
 
 // fp32 instantiation: the correction equation L e = r of the mixed-precision mode (same tiles:
 // half the LDS and HBM bytes per point, the same instruction count)

@@ -152,12 +152,19 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
-    function ndsmk_fused_window(g, u, uout, rhs, nsweeps, z0, z1, px, uc) bind(c, name="ndsmk_fused_window") result(rc)
+    function ndsmk_fused_window(g, u, uout, rhs, nsweeps, z0, z1, px, uc, prev, accumulate) &
+        bind(c, name="ndsmk_fused_window") result(rc)
       import :: ndsmk_grid, c_ptr, c_int
       type(ndsmk_grid), intent(in) :: g
-      type(c_ptr), value :: u, uout, rhs, px, uc
-      integer(c_int), value :: nsweeps, z0, z1
+      type(c_ptr), value :: u, uout, rhs, px, uc, prev
+      integer(c_int), value :: nsweeps, z0, z1, accumulate
       integer(c_int) :: rc
+    end function
+
+    function ndsmk_fused_metric_ok(g) bind(c, name="ndsmk_fused_metric_ok") result(ok)
+      import :: ndsmk_grid, c_int
+      type(ndsmk_grid), intent(in) :: g
+      integer(c_int) :: ok
     end function
 
     function ndsmk_fused_prolong_ok(g, rhs, nsweeps) bind(c, name="ndsmk_fused_prolong_ok") result(ok)

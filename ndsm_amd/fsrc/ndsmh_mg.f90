@@ -25,7 +25,7 @@ module ndsmh_mg
   private
 
   public :: mg_solver, mg_create, mg_destroy, mg_vcycle, mg_solve
-  public :: mg_mixed_applies, mg_relax_window, mg_swap_u, mg_window_prolong_ok
+  public :: mg_mixed_applies, mg_relax_window, mg_swap_u, mg_window_prolong_ok, mg_window_metric_ok
   public :: mg_set_u, mg_set_rhs, mg_get_u, mg_zero_rhs, mg_level_ptr, mg_op, mg_read_info
   public :: mg_mark_rhs_set
   public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
@@ -589,23 +589,38 @@ contains
   ! src = src_n whole coarse planes starting at global coarse plane src_k0, which must cover the
   ! brackets of the window's planes and of the ghost planes the launch reads) - only where
   ! mg_window_prolong_ok says so
-  function mg_relax_window(s, n, z0, z1, src, src_k0, src_n) result(rc)
+  ! met: 0 no metric; 1 / 2 the launch also evaluates max / sum of |u_new - s%prev| over the planes it
+  ! stores and leaves it on the device (1) or adds it to what is there (2) - mg_window_metric_ok
+  function mg_relax_window(s, n, z0, z1, src, src_k0, src_n, met) result(rc)
     type(mg_solver), intent(inout), target :: s
     integer, intent(in) :: n, z0, z1
     type(c_ptr), intent(in), optional :: src
-    integer, intent(in), optional :: src_k0, src_n
+    integer, intent(in), optional :: src_k0, src_n, met
     integer(c_int) :: rc
     type(ndsmk_xfer), target :: x
+    type(c_ptr) :: pv
+    integer(c_int) :: acc
+    pv = c_null_ptr; acc = 0
+    if (present(met)) then
+      if (met /= 0) pv = s%prev
+      if (met == 2) acc = 1
+    end if
     if (present(src)) then
       x = s%xf(1)%x
       x%c_k0 = src_k0
       x%c_cnt = src_n
       rc = ndsmk_fused_window(s%lev(1)%g, s%dl(1)%u, s%dl(1)%ualt, rhs_of(s, 1), int(n, c_int), int(z0, c_int), &
-                              int(z1, c_int), c_loc(x), src)
+                              int(z1, c_int), c_loc(x), src, pv, acc)
     else
       rc = ndsmk_fused_window(s%lev(1)%g, s%dl(1)%u, s%dl(1)%ualt, rhs_of(s, 1), int(n, c_int), int(z0, c_int), &
-                              int(z1, c_int), c_null_ptr, c_null_ptr)
+                              int(z1, c_int), c_null_ptr, c_null_ptr, pv, acc)
     end if
+  end function
+
+  function mg_window_metric_ok(s) result(ok)
+    type(mg_solver), intent(in) :: s
+    logical :: ok
+    ok = ndsmk_fused_metric_ok(s%lev(1)%g) /= 0
   end function
 
   ! can a pass of n sweeps over this slab fold the prolongation in? (two sweeps, Laplace problem)

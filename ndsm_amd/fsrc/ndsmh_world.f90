@@ -127,6 +127,9 @@ module ndsmh_world
     ! post-smoothing): whole coarse planes starting at global coarse plane psk0, psn of them
     type(c_ptr), allocatable :: psrc(:)
     integer, allocatable :: psk0(:), psn(:)
+    ! world_solve asks (want_met) the last smoothing pass of the cycle to evaluate update_u's metric
+    ! against prev while it stores the new iterate; met_done says it did (else a pass of its own)
+    logical :: want_met = .false., met_done = .false.
   end type
 
 contains
@@ -534,19 +537,22 @@ contains
   ! fold it in (two sweeps, Laplace problem) it reads the UNCORRECTED u - ghosts included, their
   ! correction is formed locally from the same coarse planes the neighbour uses - and adds P u_c to
   ! every plane as it loads it; otherwise the stand-alone kernel corrects the owned planes first.
-  function world_relax(w, nsweeps, with_res, prolong) result(rc)
+  function world_relax(w, nsweeps, with_res, prolong, last) result(rc)
     type(mg_world), intent(inout) :: w
     integer, intent(in) :: nsweeps
-    logical, intent(in), optional :: with_res, prolong
+    logical, intent(in), optional :: with_res, prolong, last
     integer(c_int) :: rc
-    integer :: left, n, i, d
-    logical :: res, two_ok, pro, pend
+    integer :: left, n, i, d, mt
+    logical :: res, two_ok, pro, pend, fin, domet
     type(c_ptr) :: tmp
     rc = 0
     res = .false.
     if (present(with_res)) res = with_res
     pend = .false.
     if (present(prolong)) pend = prolong
+    fin = .false.
+    if (present(last)) fin = last
+    w%met_done = .false.
     two_ok = w%plan(0)%g >= 4
     left = nsweeps
     if (pend .and. left <= 0) then
@@ -566,6 +572,16 @@ contains
         end if
         pend = .false.
       end if
+      ! the pass that ends the cycle carries the convergence metric (mt: 1 = first launch of the
+      ! pass in this process, 2 = add to it)
+      domet = fin .and. left == n .and. .not. pro .and. .not. res
+      if (domet) then
+        do i = 1, w%nlocal
+          domet = domet .and. mg_window_metric_ok(w%loc(i))
+        end do
+      end if
+      mt = 0
+      if (domet) mt = 1
       if (res .and. left == 1) then
         rc = need_ghosts(w, 3); if (rc /= 0) return
         do i = 1, w%nlocal
@@ -583,28 +599,32 @@ contains
         if (rc /= 0) return
         do i = 1, w%nlocal
           associate (s => w%loc(i))
-            rc = window_pass(w, i, n, int(s%lev(1)%g%zown0) + d, int(s%lev(1)%g%zown1) - d, pro); if (rc /= 0) return
+            rc = window_pass(w, i, n, int(s%lev(1)%g%zown0) + d, int(s%lev(1)%g%zown1) - d, pro, mt); if (rc /= 0) return
+            if (mt == 1) mt = 2
           end associate
         end do
         rc = ndsmk_stream_fence(1_c_int, 0_c_int); if (rc /= 0) return
         do i = 1, w%nlocal
           associate (s => w%loc(i))
-            rc = window_pass(w, i, n, int(s%lev(1)%g%zown0), int(s%lev(1)%g%zown0) + d, pro); if (rc /= 0) return
-            rc = window_pass(w, i, n, int(s%lev(1)%g%zown1) - d, int(s%lev(1)%g%zown1), pro); if (rc /= 0) return
+            rc = window_pass(w, i, n, int(s%lev(1)%g%zown0), int(s%lev(1)%g%zown0) + d, pro, mt); if (rc /= 0) return
+            rc = window_pass(w, i, n, int(s%lev(1)%g%zown1) - d, int(s%lev(1)%g%zown1), pro, mt); if (rc /= 0) return
             call mg_swap_u(s)
           end associate
         end do
       else
         rc = need_ghosts(w, 2 * n); if (rc /= 0) return
         do i = 1, w%nlocal
-          if (pro) then
-            rc = window_pass(w, i, n, int(w%loc(i)%lev(1)%g%zown0), int(w%loc(i)%lev(1)%g%zown1), pro); if (rc /= 0) return
+          if (pro .or. domet) then
+            rc = window_pass(w, i, n, int(w%loc(i)%lev(1)%g%zown0), int(w%loc(i)%lev(1)%g%zown1), pro, mt)
+            if (rc /= 0) return
+            if (mt == 1) mt = 2
             call mg_swap_u(w%loc(i))
           else
             rc = mg_op(w%loc(i), MG_OP_RELAX_FUSED, 1, n); if (rc /= 0) return
           end if
         end do
       end if
+      if (domet) w%met_done = .true.
       if (w%protect) then              ! first pass of a solve-loop cycle: keep its input (see mg_world)
         do i = 1, w%nlocal
           tmp = w%loc(i)%dl(1)%ualt; w%loc(i)%dl(1)%ualt = w%loc(i)%prev; w%loc(i)%prev = tmp
@@ -617,15 +637,15 @@ contains
   end function
 
   ! one fused pass over local planes [z0, z1) of slab i, u -> ualt, optionally interpolating
-  function window_pass(w, i, n, z0, z1, pro) result(rc)
+  function window_pass(w, i, n, z0, z1, pro, mt) result(rc)
     type(mg_world), intent(inout) :: w
-    integer, intent(in) :: i, n, z0, z1
+    integer, intent(in) :: i, n, z0, z1, mt
     logical, intent(in) :: pro
     integer(c_int) :: rc
     if (pro) then
       rc = mg_relax_window(w%loc(i), n, z0, z1, w%psrc(i), w%psk0(i), w%psn(i))
     else
-      rc = mg_relax_window(w%loc(i), n, z0, z1)
+      rc = mg_relax_window(w%loc(i), n, z0, z1, met=mt)
     end if
   end function
 
@@ -704,7 +724,7 @@ contains
       end do
     end if
     w%ghost_depth = 0
-    rc = world_relax(w, w%loc(1)%ms, prolong=.true.)
+    rc = world_relax(w, w%loc(1)%ms, prolong=.true., last=w%want_met)
   end function
 
   ! V-cycles to tolerance; every rank returns the same du history
@@ -736,10 +756,16 @@ contains
           rc = ndsmk_d2d(w%loc(i)%prev, w%loc(i)%dl(1)%u, int(w%loc(i)%npts1, c_size_t) * R8); if (rc /= 0) return
         end do
       end if
-      rc = world_vcycle(w); if (rc /= 0) return
+      w%want_met = rot              ! the rotation is what leaves the cycle's starting iterate in prev
+      rc = world_vcycle(w)
+      w%want_met = .false.
+      if (rc /= 0) return
       w%protect = .false.
       tot = 0
-      do i = 1, w%nlocal
+      if (w%met_done) then            ! left on the device by the cycle's last smoothing pass
+        rc = ndsmk_fetch_fused_metric(tot); if (rc /= 0) return
+      end if
+      do i = 1, merge(0, w%nlocal, w%met_done)
         associate (s => w%loc(i))
           off = int(s%sl%g, c_size_t) * int(s%plane1, c_size_t) * R8
           nown = int(s%sl%z1 - s%sl%z0, ik) * s%plane1
