@@ -517,15 +517,24 @@ contains
     logical :: ok
     integer :: i, st
     character(len=8) :: env
+    logical :: forced
     ok = .false.
     if (w%nranks < 2) return
+    forced = .false.
     call get_environment_variable("NDSM_HIP_OVERLAP", env, status=st)
     if (st == 0) then
       if (env(1:1) == '0') return
+      forced = .true.
     end if
     do i = 1, w%nlocal
       if (w%loc(i)%sl%z1 - w%loc(i)%sl%z0 - 2 * d < 8) return
     end do
+    ! Splitting a pass into interior + two edge launches costs ~0.1 ms per slab (the edge launches
+    ! walk 8 warm-up planes for d owned ones; measured in loop-back), i.e. what an xGMI link
+    ! (~150 GB/s) needs for ~16 MB: below that the exchange is cheaper exposed than hidden.
+    if (.not. forced) then
+      if (int(d, ik) * w%loc(1)%plane1 * 8_ik < 16_ik * 1024_ik * 1024_ik) return
+    end if
     ok = .true.
   end function
 

@@ -102,7 +102,7 @@ def _check_against_single(hip, out, world, cases):
 def test_ranks_on_one_gpu_bitwise(hip, tmp_path, world):
     """level 1 in slabs, levels >= 2 on rank 0; with and without the overlapped halo exchange"""
     cases = [
-        {"ns": [64, 48, 96], "bcs": "NDDNDD"},
+        {"ns": [64, 48, 96], "bcs": "NDDNDD", "env": {"NDSM_HIP_OVERLAP": "1"}},
         {"ns": [64, 48, 96], "bcs": "DDNDDN", "env": {"NDSM_HIP_OVERLAP": "0"}},
         {"ns": [67, 40, 72], "bcs": "DNDDND", "laplace": True},
     ]
