@@ -68,22 +68,16 @@ def cpu_baseline(seconds_budget=12.0):
     rng = np.random.default_rng(2112)
     u = rng.uniform(-1, 1, (n, n, n))
     rhs = np.random.default_rng(2113).uniform(-1, 1, (n, n, n))
-    u = orc.relax3d(u, rhs, mesh, "NDDNDD")       # warm-up (thread team, page faults)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    u = orc.relax3d(u, rhs, mesh, "NDDNDD", inplace=True)       # warm-up (thread team, page faults)
     sweeps, t0 = 0, time.perf_counter()
     while True:
-        u = orc.relax3d(u, rhs, mesh, "NDDNDD")
+        orc.relax3d(u, rhs, mesh, "NDDNDD", inplace=True)      # in place, as the reference's solver calls it
         sweeps += 1
         el = time.perf_counter() - t0
         if el > seconds_budget or sweeps >= 2000:
             break
-    # each call copies u once in the ctypes wrapper; time that copy and subtract
-    t1 = time.perf_counter()
-    for _ in range(3):
-        _ = u.copy()
-    copy_t = (time.perf_counter() - t1) / 3
-    per_sweep = el / sweeps - copy_t
-    if per_sweep < 0.5 * el / sweeps:      # a copy that slow is not what the wrapper paid: leave it in
-        per_sweep = el / sweeps
+    per_sweep = el / sweeps
     out = {"value": n ** 3 / per_sweep, "unit": "LUP/s", "cores": orc.threads, "kind": kind,
            "sample": f"{sweeps} sweeps of red_black_gauss_3D at {n}^3, BCs NDDNDD, "
                      f"OMP_NUM_THREADS={orc.threads} ({usable_cpus(10**6)} usable host CPUs)",

@@ -128,8 +128,9 @@ class Oracle:
             out.append(lv)
         return shapes, out
 
-    def relax3d(self, u, rhs, mesh, bcs):
-        u = _f64(u).copy()
+    def relax3d(self, u, rhs, mesh, bcs, inplace=False):
+        """one red+black sweep; inplace=True updates the caller's (float64, C-contiguous) array - timing runs"""
+        u = _f64(u) if inplace else _f64(u).copy()
         rhs = _f64(rhs)
         ns = self._shape(u.shape[::-1])
         x, y, z = _xyz(mesh)
