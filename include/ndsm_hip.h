@@ -185,14 +185,13 @@ int ndsm_hip_world_slab(void *handle, int ilocal, int *info12);   /* its plan ro
 /* which: 0 = u, 1 = rhs, 2 = residual.  host holds nplanes whole x-y planes starting at GLOBAL
  * plane gz0; the planes that fall into slab ilocal's window (ghosts included) are copied. */
 int ndsm_hip_world_upload(void *handle, int ilocal, int which, const double *host, int gz0, int nplanes);
-int ndsm_hip_world_download(void *handle, int ilocal, int which, double *host /* Mixed precision on the slabs (BASELINE config[4]): as ndsm_hip_mg_set_precision - 0 fp64, != 0 fp64
+int ndsm_hip_world_download(void *handle, int ilocal, int which, double *host /* owned planes */);
+/* Mixed precision on the slabs (BASELINE config[4]): as ndsm_hip_mg_set_precision - 0 fp64, != 0 fp64
  * residual + fp32 correction V-cycle on level 1 (halo exchange, restriction and prolongation of the
  * correction in fp32, everything from level 2 down unchanged).  Returns 1 if ndsm_hip_world_solve will
  * run mixed, 0 if the fp64 path stays (a slab out of the fp32 kernels' reach), < 0 bad arguments.
  * Same bits as the single-domain mixed mode. */
 int ndsm_hip_world_set_precision(void *world, int mode);
-
-/* owned planes */);
 int ndsm_hip_world_zero_rhs(void *handle);                        /* as ndsm_hip_mg_zero_rhs */
 int ndsm_hip_world_relax(void *handle, int nsweeps);              /* collective */
 int ndsm_hip_world_vcycle(void *handle, int ncycles);             /* collective, asynchronous */

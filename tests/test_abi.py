@@ -27,6 +27,12 @@ def declared_functions():
     return sorted(set(re.findall(r"\b(ndsm_[a-z0-9_]+|get_[a-z0-9_]+)\s*\(", src)))
 
 
+def test_header_is_valid_c():
+    """the boundary is a C header: it must compile as C99 (and as C++) on its own"""
+    for lang, std in (("c", "-std=c99"), ("c++", "-std=c++11")):
+        subprocess.check_call(["gcc", "-fsyntax-only", "-x", lang, std, "-Wall", "-Werror", HEADER])
+
+
 def test_header_symbols_exported(lib):
     names = declared_functions()
     assert len(names) >= 13 + 15
