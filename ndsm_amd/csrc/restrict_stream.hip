@@ -260,7 +260,7 @@ __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const TF *__restrict
 #undef RS_STORE
 }
 
-constexpr int kCI = 64, kCJ = 16, kMT = 5, kKCMax = 64;
+constexpr int kCI = 64, kCJ = 8, kMT = 5, kKCMax = 64;
 
 }  // namespace
 
@@ -297,7 +297,15 @@ static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
   // coarse planes per chunk: one workgroup per CU at a time (LDS), a chunk of kc coarse planes
   // walks ~2 kc + 3 fine planes: minimise (rounds of workgroups) x (planes walked); the chunk's
   // z tables must fit their LDS arrays (kc <= kKCMax)
-  const int64_t slots = ndsm::cu_count();
+  static int occ = 0;
+  if (!occ) {
+    int o = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, restrict_stream_k<TF, kCI, kCJ, kMT, kKCMax>, kCI * kCJ,
+                                                     sizeof(double) * 2 * (2 * kCI + 6) * (2 * kCJ + 5)) != hipSuccess || o < 1)
+      o = 1;
+    occ = o;
+  }
+  const int64_t slots = (int64_t)ndsm::cu_count() * occ;
   int kc = x->c_cnt < kKCMax ? x->c_cnt : kKCMax;
   int64_t best = -1;
   for (int c = 1; c <= x->c_cnt; ++c) {
