@@ -825,6 +825,35 @@ def test_slab_world_mixed_precision_bitwise(hip, ns, nranks, levels):
 
 
 @pytest.mark.gpu
+def test_world_precision_and_distributed_entry_argument_handling(hip):
+    """mixed precision is refused (0, fp64 stays, same bits) where a slab is out of the fp32 kernels' reach;
+    the distributed pipeline entry with nranks = 1 is ndsm_vector_solve, bad ranks come back as codes"""
+    import ndsm_amd
+    ns = [33, 40, 64]                                  # odd nx, < 64 points per row: no fp32 kernels
+    mesh = uniform_mesh(ns)
+    u = rand_field(tuple(ns[::-1]), 5)
+    W, W2 = hip.World(ns, mesh, "NDDNDD", 2), hip.World(ns, mesh, "NDDNDD", 2)
+    assert W.set_precision(1) is False
+    with pytest.raises(hip.NdsmHipError):
+        W.set_precision(7)
+    for X in (W, W2):
+        X.upload(hip.BUF_U, u)
+        X.zero_rhs()
+    a, b = W.solve(nmax=3, hist_len=4), W2.solve(nmax=3, hist_len=4)
+    assert list(a[3]) == list(b[3]) and np.array_equal(W.download(hip.BUF_U), W2.download(hip.BUF_U))
+    W.close()
+    W2.close()
+    x, y, z, A1, b1 = analytic_case([24, 20, 28])
+    ierr, A, B = ndsm_amd.vector_potential(x, y, z, b1.copy())
+    ierr1, As, Bs = ndsm_amd.vector_potential_slab(x, y, z, b1, 0, 1)
+    assert ierr == ierr1 and np.array_equal(A, As) and np.array_equal(B, Bs)
+    with pytest.raises(hip.NdsmHipError):
+        ndsm_amd.vector_potential_slab(x, y, z, b1, 3, 2)          # rank >= nranks
+    with pytest.raises(hip.NdsmHipError):
+        ndsm_amd.vector_potential_slab(x, y, z, b1[:, :14], 0, 2)  # no communicator in this process
+
+
+@pytest.mark.gpu
 def test_random_slab_worlds(hip):
     """seeded random shapes, 2..8 slabs, 1..3 distributed levels, exchange overlap on or off, random ms and
     face letters: three solve-loop cycles of the loop-back world return the single-domain solver's du
