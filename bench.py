@@ -14,9 +14,13 @@ value = fine-grid lattice-point updates per second over the WHOLE V-cycle:
         (coarse levels, residual, transfers, the convergence metric of update_u
         and the host's read-back of it are all inside the timed region and count
         as overhead, not as updates).
-Extra keys: vcycles_per_s, smoother (kernel-only, HIP events), roofline of the
-dominant kernel (level-1 RB-GS sweep, 24 B/LUP algorithmic), cpu_baseline (the
-reference's own smoother timed on this box's host cores).
+Extra keys: vcycles_per_s, smoother (kernel-only, HIP events on the library
+stream), roofline = the kernel that dominates the timed region (two-sweep
+Laplace launch of level 1, 16 B/LUP algorithmic; frac_algorithmic and frac_hbm
+side by side), roofline_general_rhs (the same launch with a right-hand side in
+HBM, 24 B/LUP), solve (whole Ax solve to vc_tol=1e-10), end_to_end
+(ndsm_vector_solve wall time, host buffers in and out), cpu_baseline (the
+reference itself on this box's host cores, on the same 512^3 grid).
 
 One process per GPU.  N > 1: see DESIGN.md section "multi-GPU".
 """
@@ -57,18 +61,18 @@ def boundary_problem(n):
     return [x, y, z], u
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """Reference smoother (red_black_gauss_3D, ndsm_optimized.f90:40) on this
-    box's host cores; falls back to the C port if oracle/_ref is absent."""
+def cpu_baseline(n=512, seconds_budget=8.0):
+    """The reference itself (oracle/_ref: red_black_gauss_3D, ndsm_optimized.f90:40, and solve_poisson_bvp,
+    ndsm_poisson.f90:63) on this box's host cores, ON THE BENCHMARKED GRID (n^3); falls back to the C
+    port if oracle/_ref is absent.  A bounded sample: ~seconds_budget of smoother sweeps + ONE pass of the
+    reference's solve loop (V-cycle + update_u)."""
     from oracle import Oracle, have_ref, usable_cpus
     kind = "reference" if have_ref() else "port"
     orc = Oracle("ref" if have_ref() else "port")
-    n = 256
-    mesh = [np.linspace(0, 1, n)] * 3
+    mesh, u0 = boundary_problem(n)
     rng = np.random.default_rng(2112)
     u = rng.uniform(-1, 1, (n, n, n))
     rhs = np.random.default_rng(2113).uniform(-1, 1, (n, n, n))
-    u = np.ascontiguousarray(u, dtype=np.float64)
     u = orc.relax3d(u, rhs, mesh, "NDDNDD", inplace=True)       # warm-up (thread team, page faults)
     sweeps, t0 = 0, time.perf_counter()
     while True:
@@ -78,24 +82,61 @@ def cpu_baseline(seconds_budget=12.0):
         if el > seconds_budget or sweeps >= 2000:
             break
     per_sweep = el / sweeps
-    out = {"value": n ** 3 / per_sweep, "unit": "LUP/s", "cores": orc.threads, "kind": kind,
-           "sample": f"{sweeps} sweeps of red_black_gauss_3D at {n}^3, BCs NDDNDD, "
+    out = {"value": n ** 3 / per_sweep, "unit": "LUP/s", "cores": orc.threads, "kind": kind, "grid": f"{n}^3",
+           "sample": f"{sweeps} sweeps of red_black_gauss_3D at {n}^3 (the benchmarked grid), BCs NDDNDD, "
                      f"OMP_NUM_THREADS={orc.threads} ({usable_cpus(10**6)} usable host CPUs)",
            "ms_per_sweep": per_sweep * 1e3}
-    # SURVEY 8d also asks for s/V-cycle: ONE pass of the reference's solve loop (V-cycle + update_u) at
-    # 128^3 - its generic restriction / interpolation dominate it, so this is context
-    # for whole-solve ratios, not a smoother comparison
+    del u, rhs
+    # SURVEY 8d also asks for s/V-cycle: ONE pass of the reference's solve loop (V-cycle + update_u) on the
+    # timed workload itself (Ax Laplace problem, n^3) - its generic restriction / interpolation dominate
+    # it, so this is context for whole-solve ratios, not a smoother comparison
     try:
-        m = 128
-        mesh = [np.linspace(0, 1, m)] * 3
-        u0 = np.random.default_rng(7).uniform(-1, 1, (m, m, m))
         t0 = time.perf_counter()
         orc.solve_bvp(u0, np.zeros_like(u0), mesh, "NDDNDD", ms=5, nmax=1)
         out["vcycle_s"] = time.perf_counter() - t0
-        out["vcycle_sample"] = f"one V-cycle + update_u of solve_poisson_bvp at {m}^3 (ms=5), same threads"
+        out["vcycle_sample"] = f"one V-cycle + update_u of solve_poisson_bvp at {n}^3 (ms=5), Ax Laplace problem, same threads"
     except Exception as exc:  # noqa: BLE001
         out["vcycle_sample"] = f"not timed: {type(exc).__name__}: {exc}"
     return out
+
+
+def end_to_end(L, n):
+    """ndsm_vector_solve - the reference's actual entry point - at n^3 through raw ctypes, host buffers in
+    and out (PCIe inclusive): wall time of the FIRST call in this process and of a SECOND call on the same
+    mesh (hierarchy, tables and device pool cached inside the library)."""
+    import ctypes
+    from golden_inputs import analytic_case
+    x, y, z, _A1, b1 = analytic_case(n)
+    del _A1
+    nshape = np.array([n, n, n, 3], dtype=np.intc)
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    L.ndsm_vector_solve.argtypes = [ctypes.c_size_t, ip, ip, dp, dp, dp, dp, dp, dp]
+    L.ndsm_vector_solve.restype = ctypes.c_int
+    times, ncyc = [], None
+    A = np.empty(b1.size)
+    B = np.empty(b1.size)
+    for _ in range(2):
+        ioptc = np.zeros(16, dtype=np.intc)
+        ropt = np.zeros(16)
+        ioptc[L.get_iopt_ms()] = 5
+        ioptc[L.get_iopt_ncycles()] = 1024
+        ioptc[L.get_iopt_iopt_nmaxex()] = 10000
+        ioptc[L.get_iopt_dumax()] = 1
+        ropt[L.get_ropt_vtol()] = 1e-10
+        ropt[L.get_ropt_ctol()] = 1e-13
+        A[:] = 0.0
+        B[:] = b1.ravel()
+        t0 = time.perf_counter()
+        ierr = L.ndsm_vector_solve(ctypes.c_size_t(B.size), nshape.ctypes.data_as(ip), ioptc.ctypes.data_as(ip),
+                                   ropt.ctypes.data_as(dp), x.ctypes.data_as(dp), y.ctypes.data_as(dp),
+                                   z.ctypes.data_as(dp), A.ctypes.data_as(dp), B.ctypes.data_as(dp))
+        times.append(time.perf_counter() - t0)
+        if ierr != 0:
+            return {"error": f"ndsm_vector_solve returned {ierr}"}
+        ncyc = int(ioptc[L.get_iopt_ncyc_out()])
+    return {"e2e_s": times[0], "e2e_second_call_s": times[1], "ncycles_last_3d_solve": ncyc,
+            "what": f"ndsm_vector_solve at {n}^3, host buffers in and out (the initial guess A up unless it is all zero, 6 GiB of "
+                    "A and B down over PCIe, six 2-D + three 3-D solves to vc_tol=1e-10, flux balance, curl); second call = same mesh again"}
 
 
 def slab_window_problem(n3, sl):
@@ -179,13 +220,25 @@ def main():
     ap.add_argument("--n", type=int, default=512, help="points per dimension of the fine grid (1 GPU)")
     ap.add_argument("--ms", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-solve / ndsm_vector_solve timings")
     args = ap.parse_args()
+
+    # ONE JSON line on stdout: everything else this process and the native libraries under it write to
+    # file descriptor 1 (the reference's and our Fortran `PRINT *` warnings, flushed at exit) goes to
+    # stderr; the result line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        # one process per GPU: the launcher (python -m torch.distributed.run --nproc-per-node N) starts the
+        # ranks; a lone process asked for N GPUs must not report a 1-GPU number as an N-GPU one
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                         f"--master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
 
     # libndsm_hip FIRST: it loads /opt/rocm's libamdhip64.so.7 / librccl.so.1.  PyTorch bundles a
     # second ROCm stack under the same SONAMEs; whichever is loaded first serves the whole process,
@@ -194,13 +247,16 @@ def main():
     import ndsm_amd
     from ndsm_amd import _lib
     L = ndsm_amd.load_library()
-    rc = L.ndsm_hip_init(local_rank % max(1, L.ndsm_hip_device_count()))
+    ndev = L.ndsm_hip_device_count()
+    if world > 1 and ndev < world and not os.environ.get("NDSM_HIP_LIB"):   # (NDSM_HIP_LIB: the test double's rehearsal)
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPU(s) visible - one process per GPU")
+    rc = L.ndsm_hip_init(local_rank % max(1, ndev))
     if rc != 0:
         raise SystemExit("libndsm_hip: " + _lib.last_error(L))
 
     dist = None
-    rccl_ok, rccl_err, slab_mode = True, "", False
     slab_check = None
+    rccl_ranks = 0
     if world > 1:
         import faulthandler
         faulthandler.dump_traceback_later(600, exit=True)   # a wedged collective must not hang the node
@@ -213,10 +269,18 @@ def main():
         if rank == 0:
             uid = torch.frombuffer(bytearray(_lib.dist_unique_id(L)), dtype=torch.uint8).clone()
         dist.broadcast(uid, 0)
-        try:
-            _lib.dist_init(rank, world, uid.numpy().tobytes(), L)     # RCCL communicator over xGMI
-        except Exception as exc:  # noqa: BLE001
-            rccl_ok, rccl_err = False, f"{type(exc).__name__}: {exc}"
+
+    def all_ok(ok, what, err=""):
+        """every rank must succeed: the z-slab path either runs on all N GPUs or the bench FAILS - it never
+        degrades to N independent replicas behind an n_gpus = N line"""
+        import torch
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag[0]) < 0.5:
+            print(f"bench.py[rank {rank}]: {what} failed" + (f": {err}" if err else " on another rank") +
+                  " - no result line (the z-slab RCCL path did not run)", file=sys.stderr, flush=True)
+            dist.barrier()
+            raise SystemExit(3)
 
     def barrier_sync():
         _lib._check(L.ndsm_hip_sync(), "sync", L)
@@ -231,7 +295,6 @@ def main():
         S = _lib.MGSolver(n3, mesh, "NDDNDD", ms=ms)
         S.upload(1, _lib.BUF_U, u0)
         S.zero_rhs()       # the vector potential's 3-D problems are Laplace problems (rhs = 0, :640-641)
-        del u0
         # one step = one pass of the reference's solve loop (solve_poisson_bvp, ndsm_poisson.f90:104-150):
         # V-cycle + update_u's max|u_new - u_old| + the host's strict du < vc_tol test; vc_tol = 0 is never
         # met, so exactly K cycles run
@@ -241,17 +304,44 @@ def main():
                     f"{ngrids} grids), config[2] of BASELINE.json")
         parallelism = "single GPU"
         scaling = "weak"
+        slab_mode = False
     else:
         # BASELINE config[3]: 1024 x 1024 x 512 Poisson, level 1 z-slab decomposed over the ranks,
-        # RCCL halo exchange between sweeps, levels >= 2 on rank 0
+        # RCCL halo exchange between sweeps, coarse levels distributed while a rank's share is large,
+        # the rest on rank 0
+        err = ""
+        try:
+            _lib.dist_init(rank, world, uid.numpy().tobytes(), L)     # RCCL communicator over xGMI
+            rccl_ranks = _lib.dist_info(L)[1]
+            if rccl_ranks != world:
+                raise RuntimeError(f"RCCL communicator reports {rccl_ranks} ranks, expected {world}")
+        except Exception as exc:  # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"
+        all_ok(not err, "RCCL communicator bring-up", err)
+        # the distributed path against the single-GPU solver on the real transport, bit for bit - with the
+        # halo exchange on the main stream and (forced) on the second stream behind the interior planes
+        checks = []
+        for ov in ("0", "1"):
+            old = os.environ.get("NDSM_HIP_OVERLAP")
+            os.environ["NDSM_HIP_OVERLAP"] = ov
+            try:
+                checks.append(slab_self_check(_lib, L, dist, rank, world))
+            except Exception as exc:  # noqa: BLE001
+                checks.append(f"MISMATCH: self-check could not run: {type(exc).__name__}: {exc}")
+            finally:
+                if old is None:
+                    os.environ.pop("NDSM_HIP_OVERLAP", None)
+                else:
+                    os.environ["NDSM_HIP_OVERLAP"] = old
+        bad = [c for c in checks if "MISMATCH" in c]
+        all_ok(not bad, "slab self-check against the single-GPU solver", "; ".join(bad))
+        slab_check = checks[0] + " [exchange on the main stream]; " + (checks[1] or checks[0]) + " [exchange overlapped]"
         n3 = [1024, 1024, 512]
         x = np.linspace(0.0, 1.0, n3[0])
         dx = x[1] - x[0]
         mesh = [x, np.arange(n3[1]) * dx, np.arange(n3[2]) * dx]
         S, err = None, ""
         try:
-            if not rccl_ok:
-                raise RuntimeError(rccl_err)
             S = _lib.World(n3, mesh, "NDDNDD", world, rank, ms=ms, lib=L)
             _m, win, a = slab_window_problem(n3, S.slabs[0])
             S.upload_window(1, _lib.BUF_U, win, a)
@@ -261,47 +351,16 @@ def main():
             S.sync()
         except Exception as exc:  # noqa: BLE001
             err = f"{type(exc).__name__}: {exc}"
-            S = None
-        import torch
-        flag = torch.tensor([1.0 if S is not None else 0.0], dtype=torch.float64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if float(flag[0]) > 0.5:
-            run_cycles = lambda k: S.solve(vc_tol=0.0, nmax=k)  # noqa: E731
-            ngrids = 8
-            workload = (f"1024x1024x512 Poisson (Ax boundary data), one V-cycle + convergence metric per step "
-                        f"(ms={ms}), config[3] of BASELINE.json")
-            parallelism = (f"level 1 in {world} z-slabs (RCCL send/recv halo: 4 planes per neighbour per two-sweep "
-                           "pass), levels>=2 on rank 0")
-            scaling = "strong"
-            slab_mode = True
-            try:
-                slab_check = slab_self_check(_lib, L, dist, rank, world)
-            except Exception as exc:  # noqa: BLE001
-                slab_check = f"self-check could not run: {type(exc).__name__}: {exc}"
-        else:
-            # the distributed path could not be brought up on this node: say so and measure
-            # independent replicas of the 1-GPU workload instead of reporting nothing
-            if S is not None:
-                S.close()
-            if rank == 0:
-                print("bench: z-slab RCCL path unavailable (" + (err or "failed on another rank") +
-                      "); falling back to independent replicas", file=sys.stderr, flush=True)
-            n = args.n
-            n3 = [n, n, n]
-            mesh, u0 = boundary_problem(n)
-            S = _lib.MGSolver(n3, mesh, "NDDNDD", ms=ms, lib=L)
-            S.upload(1, _lib.BUF_U, u0)
-            S.zero_rhs()
-            del u0
-            run_cycles = lambda k: S.solve(vc_tol=0.0, nmax=k)  # noqa: E731
-            ngrids = S.ngrids
-            workload = f"{n}^3 vector-potential Ax component per GPU, one V-cycle + convergence metric per step (ms={ms})"
-            parallelism = f"{world} independent replicas (no exchange) - z-slab RCCL path failed to start"
-            scaling = "weak"
-            slab_mode = False
+        all_ok(not err, "z-slab world (1024x1024x512)", err)
+        run_cycles = lambda k: S.solve(vc_tol=0.0, nmax=k)  # noqa: E731
+        ngrids = 8
+        workload = (f"1024x1024x512 Poisson (Ax boundary data), one V-cycle + convergence metric per step "
+                    f"(ms={ms}), config[3] of BASELINE.json")
+        parallelism = (f"level 1 in {world} z-slabs (RCCL send/recv halo: 4 planes per neighbour per two-sweep "
+                       f"pass), {S.dist_levels} distributed level(s), the rest on rank 0")
+        scaling = "strong"
+        slab_mode = True
     npts = float(n3[0]) * n3[1] * n3[2]
-    if world > 1 and not slab_mode:
-        npts *= world           # every replica updates its own grid
 
     # ---- the timed region: K V-cycles ------------------------------------
     run_cycles(args.warmup)
@@ -317,64 +376,93 @@ def main():
         el = float(t[0])
     ms_per_step = el / args.steps * 1e3
 
-    # ---- dominant kernel: level-1 smoother sweeps under HIP events ---------
+    # ---- dominant kernel: the level-1 smoother launches under HIP events on the library stream ----
     nsw = 20
-    vc_only_ms = None
+    vc_only_ms = gen_ms = rs_ms = sweeps_per_cycle = None
+    solve_info = None
     if world == 1:
         S.vcycle(2)
         S.sync()
         vc_only_ms = S.timed(lambda: S.vcycle(args.steps)) / args.steps   # the cycle without update_u
-        # Laplace variant first (what the V-cycles above ran: rhs never read, 16 B/LUP algorithmic) ...
+        # the kernel the timed V-cycles spend most of their time in: the two-sweep LAPLACE launch (rhs
+        # declared zero and never read: 16 B/LUP algorithmic) ...
         S.op(_lib.OP_RELAX, 1, 2)
         S.sync()
         lap_ms = S.timed(lambda: S.op(_lib.OP_RELAX, 1, nsw)) / nsw
-        # ... then the general kernel with a right-hand side in HBM: the roofline line (24 B/LUP)
+        sweeps, _unconv = S.info()
+        sweeps_per_cycle = sweeps / max(1, args.steps * 2 + args.warmup + 2)
+        if not args.no_e2e:
+            # whole Ax solve to the reference's default tolerance (SURVEY 8d "total solve time")
+            S.upload(1, _lib.BUF_U, u0)
+            S.sync()
+            t0 = time.perf_counter()
+            ie, du, nc, _h = S.solve(vc_tol=1e-10, nmax=1024)
+            S.sync()
+            solve_info = {"solve_s": time.perf_counter() - t0, "ncycles": nc, "du_last": du, "ierr": ie,
+                          "what": f"{n}^3 Ax Laplace solve to vc_tol=1e-10 on the resident hierarchy (device time + 16-byte read-backs)"}
+        # ... and the general kernel with a right-hand side in HBM (level 2 of these solves; level 1 of
+        # Poisson problems): 24 B/LUP
         S.upload(1, _lib.BUF_RHS, np.random.default_rng(2113).uniform(-1, 1, (n, n, n)))
         S.op(_lib.OP_RELAX, 1, 2)
         S.sync()
-        sm_ms = S.timed(lambda: S.op(_lib.OP_RELAX, 1, nsw)) / nsw
+        gen_ms = S.timed(lambda: S.op(_lib.OP_RELAX, 1, nsw)) / nsw
         rs_ms = S.timed(lambda: [S.op(_lib.OP_RESIDUAL, 1) for _ in range(5)]) / 5
-        sweeps, unconv = S.info()
-        sweeps_per_cycle = sweeps / max(1, args.steps + args.warmup)
-    elif not slab_mode:
-        S.op(_lib.OP_RELAX, 1, 2)
-        S.sync()
-        sm_ms = S.timed(lambda: S.op(_lib.OP_RELAX, 1, nsw)) / nsw / world   # whole-job time per global sweep
-        rs_ms = None
-        lap_ms = None
-        sweeps_per_cycle = None
+        bpl = 16.0
+        kname = "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, true, 0, true, false>"
     else:
         S.relax(2)
         barrier_sync()
-        sm_ms = S.timed(lambda: S.relax(nsw)) / nsw               # includes the halo exchanges
-        if dist is not None:
-            import torch
-            t = torch.tensor([sm_ms], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sm_ms = float(t[0])
-        rs_ms = None
-        lap_ms = None
-        sweeps_per_cycle = None
-    achieved = BYTES_PER_LUP * npts / (sm_ms * 1e-3) / 1e9         # whole job
+        lap_ms = S.timed(lambda: S.relax(nsw)) / nsw               # includes the halo exchanges
+        import torch
+        t = torch.tensor([lap_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lap_ms = float(t[0])
+        bpl = 16.0
+        kname = "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, true, 0, *> on z-slab windows, halo exchange included"
     S.close()
+    del S
 
-    traffic = None
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
+    # MI355X_MICROARCH.md) - NOT measured in this run
+    traffic = traffic_gen = None
+    tsrc = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and world == 1:
+    if os.path.exists(tpath) and world == 1 and args.n == 512:
         try:
-            traffic = json.load(open(tpath)).get("smoother_sweep_bytes_per_launch")
-        except Exception:
-            traffic = None
+            tj = json.load(open(tpath))
+            for k, v in tj.get("kernels", {}).items():
+                if k.startswith("zero <double, 2"):
+                    traffic = v["total_bytes"]
+                if k.startswith("general <double, 2"):
+                    traffic_gen = v["total_bytes"]
+            tsrc = "profiles/traffic_latest.json (" + tj.get("collected", "rocprofv3 --pmc, separate passes") + "); not measured in this run"
+        except Exception:  # noqa: BLE001
+            traffic = traffic_gen = None
+
+    def roofline(ms_sweep, bytes_per_lup, kernel, tr):
+        launch_s = 2 * ms_sweep * 1e-3
+        alg = 2 * bytes_per_lup * npts / world                    # per launch and GPU: two sweeps
+        r = {"bound": "hbm", "achieved": alg / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": alg / launch_s / 1e9 / HBM_PEAK_GBS, "traffic": tr,
+             "kernel": kernel, "bytes_per_lup": bytes_per_lup, "sweeps_per_launch": 2,
+             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": launch_s * 1e3,
+             "frac_algorithmic": alg / launch_s / 1e9 / HBM_PEAK_GBS,
+             "frac_hbm": (tr / launch_s / 1e9 / HBM_PEAK_GBS) if tr else None,
+             "traffic_source": tsrc if tr else None,
+             "note": "frac = frac_algorithmic = SURVEY 8d algorithmic bytes (bytes_per_lup x 2 sweeps x points) / launch "
+                     "time / 8 TB/s: one launch performs TWO sweeps on one pass over HBM (temporal blocking), so it "
+                     "can exceed what the memory system moves; frac_hbm = HBM bytes the launch really moved "
+                     "(traffic) / launch time / 8 TB/s"}
+        return r
 
     def finish():
         # after the result line is out: leave together, then take the communicator down (collective)
         if dist is not None:
             dist.barrier()
-            if rccl_ok:
-                try:
-                    _lib.dist_finalize(L)
-                except Exception as exc:  # noqa: BLE001
-                    print(f"bench: dist_finalize: {exc}", file=sys.stderr, flush=True)
+            try:
+                _lib.dist_finalize(L)
+            except Exception as exc:  # noqa: BLE001
+                print(f"bench: dist_finalize: {exc}", file=sys.stderr, flush=True)
 
     if rank != 0:
         finish()
@@ -393,27 +481,34 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": workload, "global_points": int(npts), "parallelism": parallelism},
+        "slab_mode": slab_mode,
+        "rccl_ranks": rccl_ranks,
         "vcycles_per_s": 1.0 / (ms_per_step * 1e-3),
         "vcycle_without_metric_ms": vc_only_ms,
-        "smoother": {"ms_per_sweep": sm_ms, "LUPs_per_s": npts / (sm_ms * 1e-3), "residual_ms": rs_ms,
-                     "laplace_variant_ms_per_sweep": lap_ms,
-                     "laplace_variant_LUPs_per_s": (npts / (lap_ms * 1e-3)) if lap_ms else None},
+        "smoother": {"laplace_ms_per_sweep": lap_ms, "laplace_LUPs_per_s": npts / (lap_ms * 1e-3),
+                     "general_rhs_ms_per_sweep": gen_ms,
+                     "general_rhs_LUPs_per_s": (npts / (gen_ms * 1e-3)) if gen_ms else None,
+                     "residual_ms": rs_ms},
         "coarse_exact_sweeps_per_cycle": sweeps_per_cycle,
-        "roofline": {"bound": "hbm", "achieved": achieved / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / world / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "level-1 RB-GS sweep (red+black, fused)" + ("" if world == 1 else ", per GPU, halo exchange included"),
-                     "bytes_per_lup": BYTES_PER_LUP,
-                     "sweeps_per_launch": 2, "algorithmic_bytes_per_launch": 2 * BYTES_PER_LUP * npts / world,
-                     "avg_launch_ms": 2 * sm_ms,
-                     "note": "one launch = two full red+black sweeps (temporal blocking); traffic = HBM bytes per "
-                             "launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/traffic_latest.json"},
+        # the kernel that dominates the timed region (top row of profiles/*_kernel_stats.csv)
+        "roofline": roofline(lap_ms, bpl, kname, traffic),
         "rocm_stack": _lib.bound_libs(L),
     }
+    if gen_ms:
+        out["roofline_general_rhs"] = roofline(gen_ms, BYTES_PER_LUP,
+                                               "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, false, 0, true, false>", traffic_gen)
+    if solve_info:
+        out["solve"] = solve_info
     if slab_check is not None:
         out["slab_check"] = slab_check
+    if world == 1 and not args.no_e2e:
+        try:
+            out["end_to_end"] = end_to_end(L, args.n)
+        except Exception as exc:  # noqa: BLE001
+            out["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out), flush=True)
+        out["cpu_baseline"] = cpu_baseline(args.n)
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
     finish()
 
 

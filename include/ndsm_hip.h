@@ -86,6 +86,10 @@ int get_iopt_prec(void);     /* -> 11 in : 0 fp64 throughout (reference arithmet
 
 int ndsm_hip_device_count(void);
 int ndsm_hip_init(int device);               /* < 0: LOCAL_RANK % device count; idempotent */
+/* Releases what the library itself holds on the device (streams, events, metric scratch, the cached
+ * vector-potential hierarchy, a live RCCL communicator).  Destroy solver / world handles first.  Any
+ * later call re-initialises (ndsm_hip_init may then name another device). */
+int ndsm_hip_shutdown(void);
 void ndsm_hip_last_error(char *buf, int len);
 int ndsm_hip_sync(void);                     /* wait for the library stream */
 int ndsm_hip_timer_start(void);              /* hipEventRecord on the library stream */
@@ -147,6 +151,15 @@ int ndsm_hip_dist_init(int rank, int nranks, const void *id128);
 /* destroys the communicator after draining the library's streams; call on every rank once all
  * worlds are destroyed.  No-op without a communicator. */
 int ndsm_hip_dist_finalize(void);
+/* Collective transport self-test on the live communicator (meant for the 1-rank bring-up on a one-GPU
+ * box, valid at any size): each rank sends nelem doubles to itself and receives them back through the
+ * grouped ncclSend / ncclRecv pair a halo exchange uses, once on the main stream and once on the
+ * communication stream between two fences (the order an overlapped pass issues them in), then runs the
+ * 2-value (max, sum) all-reduce of the convergence metric.  0 = every byte arrived and the reduction is right. */
+int ndsm_hip_dist_selftest(int nelem);
+/* rank / size as the live RCCL communicator reports them (ncclCommUserRank, ncclCommCount);
+ * *nranks = 0 when no communicator is up */
+int ndsm_hip_dist_info(int *rank, int *nranks);
 
 /* Slab plan for nranks ranks, 12 ints per rank: rank, z0, z1 (owned fine planes), g (ghost
  * depth), nloc (= z1 - z0 + 2 g), k0 (global index of local plane 0), ck0, ck1 (coarse planes it
@@ -202,6 +215,18 @@ int ndsm_hip_world_solve(void *handle, double vc_tol, int nmax, double *du_last,
 /* "hip=<path>;rccl=<path>": the shared objects this library's HIP / RCCL calls are bound to
  * (a process that also imports PyTorch holds two ROCm stacks) */
 int ndsm_hip_bound_libs(char *buf, int len);
+
+/* =====================================================================
+ * PART 4 - development hooks (tests and tuning; no reference counterpart)
+ * ===================================================================== */
+
+/* Tile configuration of the fused smoother (csrc/smooth_fused.hip), the five values of the
+ * NDSM_FUSED_CFG environment variable at run time: alternates for the two-sweep / one-sweep /
+ * sweep+residual launches (0 = default), a fixed number of work items (0 = the launch's own choice),
+ * and big = -1 by level size / 0 never / 1 always use the tiles of >= 64 M-point levels - so that the
+ * parity tests can run the benchmarked 512^3 configurations on grids the oracle handles.
+ * Results never depend on these values (bit for bit); only speed does. */
+int ndsm_hip_debug_fused_cfg(int two, int one, int res, int work_items, int big);
 
 #ifdef __cplusplus
 }

@@ -333,6 +333,14 @@ def dist_init(rank, nranks, uid, lib=None):
     _check(L.ndsm_hip_dist_init(int(rank), int(nranks), ctypes.c_char_p(uid)), "ndsm_hip_dist_init", L)
 
 
+def dist_info(lib=None):
+    """(rank, nranks) as the RCCL communicator itself reports them; nranks == 0: none is up"""
+    L = lib or load_library()
+    r, n = ctypes.c_int(0), ctypes.c_int(0)
+    _check(L.ndsm_hip_dist_info(ctypes.byref(r), ctypes.byref(n)), "ndsm_hip_dist_info", L)
+    return r.value, n.value
+
+
 def dist_finalize(lib=None):
     L = lib or load_library()
     _check(L.ndsm_hip_dist_finalize(), "ndsm_hip_dist_finalize", L)

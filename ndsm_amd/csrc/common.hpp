@@ -14,6 +14,20 @@ namespace ndsm {
 hipStream_t stream();
 bool ready();
 int cu_count();
+// Device-bound process state.  epoch() changes every time the runtime comes up on a device
+// (ndsmk_init after ndsmk_shutdown, or a re-target): per-kernel attributes cached in function statics
+// are re-issued when their stored epoch differs.  at_reset(fn): fn runs once at the next shutdown /
+// re-target, while the old device is still current and its streams are drained - scratch allocations
+// that live in a translation unit's globals register their release there.
+int epoch();
+void at_reset(void (*fn)());
+// true once per epoch and call site: `static int ep = 0; if (ndsm::first_in_epoch(ep)) { ... }`
+inline bool first_in_epoch(int &seen) {
+  const int e = epoch();
+  if (seen == e) return false;
+  seen = e;
+  return true;
+}
 int fail(int code, const char *what, const char *file, int line);
 int not_ready(const char *file, int line);
 

@@ -16,6 +16,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 namespace {
 
@@ -26,6 +27,14 @@ struct Dist {
   double *d_red = nullptr;  // 2 doubles
 };
 Dist g_d;
+
+// the runtime is shutting down or re-targeting with a live communicator: take it down with the device
+void dist_release() {
+  if (!g_d.up) return;
+  ncclCommDestroy(g_d.comm);
+  (void)hipFree(g_d.d_red);
+  g_d = Dist();
+}
 
 int nccl_fail(ncclResult_t r, const char *file, int line) {
   return ndsm::fail(NDSMK_ENCCL, ncclGetErrorString(r), file, line);
@@ -63,15 +72,14 @@ int ndsmk_dist_init(int rank, int nranks, const void *id128) {
   g_d.rank = rank;
   g_d.size = nranks;
   g_d.up = true;
+  ndsm::at_reset(dist_release);
   return 0;
 }
 
 int ndsmk_dist_finalize(void) {
   if (!g_d.up) return 0;
   (void)ndsmk_sync();
-  ncclCommDestroy(g_d.comm);
-  (void)hipFree(g_d.d_red);
-  g_d = Dist();
+  dist_release();
   return 0;
 }
 
@@ -85,6 +93,17 @@ int ndsmk_bound_libs(char *buf, int len) {
   if (dladdr(reinterpret_cast<void *>(&hipStreamSynchronize), &a) && a.dli_fname) ha = a.dli_fname;
   if (dladdr(reinterpret_cast<void *>(&ncclGetUniqueId), &b) && b.dli_fname) hb = b.dli_fname;
   std::snprintf(buf, (size_t)len, "hip=%s;rccl=%s", ha, hb);
+  return 0;
+}
+
+// what the COMMUNICATOR says (ncclCommUserRank / ncclCommCount), not what the caller passed to
+// ndsmk_dist_init: *nranks = 0 without a communicator
+int ndsmk_dist_info(int *rank, int *nranks) {
+  *rank = 0;
+  *nranks = 0;
+  if (!g_d.up) return 0;
+  NDSM_NCCL(ncclCommUserRank(g_d.comm, rank));
+  NDSM_NCCL(ncclCommCount(g_d.comm, nranks));
   return 0;
 }
 
@@ -136,6 +155,54 @@ int ndsmk_dist_allreduce_max_sum(double *h_ms) {
   NDSM_NCCL(ncclAllReduce(g_d.d_red + 1, g_d.d_red + 1, 1, ncclDouble, ncclSum, g_d.comm, s));
   NDSM_HIP(hipMemcpyAsync(h_ms, g_d.d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   NDSM_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// Transport self-test on the LIVE communicator (any size, meant for the 1-rank bring-up on a one-GPU
+// box): every rank sends `nelem` doubles to itself and receives them back through the same grouped
+// ncclSend / ncclRecv pair a halo exchange uses - first on the main stream, then on the communication
+// stream between two fences, the order an overlapped pass issues them in - and the 2-value all-reduce
+// runs once.  Returns 0 if every byte arrived and the all-reduce returned (max, sum x size) of its input.
+int ndsmk_dist_selftest(int nelem) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(g_d.up && nelem > 0);
+  const size_t n = (size_t)nelem;
+  std::vector<double> h(n), back(n);
+  for (size_t i = 0; i < n; ++i) h[i] = 1.0 + 1e-3 * (double)i + (double)g_d.rank;
+  double *src = nullptr, *dst = nullptr;
+  NDSM_HIP(hipMalloc((void **)&src, n * sizeof(double)));
+  NDSM_HIP(hipMalloc((void **)&dst, n * sizeof(double)));
+  int rc = 0;
+  for (int pass = 0; pass < 2 && !rc; ++pass) {
+    rc = ndsmk_h2d(src, h.data(), n * sizeof(double));
+    if (!rc) rc = ndsmk_fill0(dst, n * sizeof(double));
+    if (!rc && pass == 1) rc = ndsmk_stream_fence(0, 1);
+    if (!rc && pass == 1) rc = ndsmk_select_stream(1);
+    if (!rc) {
+      ncclResult_t r = ncclGroupStart();
+      if (r == ncclSuccess) r = ncclSend(src, n, ncclDouble, g_d.rank, g_d.comm, ndsm::stream());
+      if (r == ncclSuccess) r = ncclRecv(dst, n, ncclDouble, g_d.rank, g_d.comm, ndsm::stream());
+      const ncclResult_t e = ncclGroupEnd();
+      if (r == ncclSuccess) r = e;
+      if (r != ncclSuccess) rc = nccl_fail(r, __FILE__, __LINE__);
+    }
+    if (pass == 1) {
+      (void)ndsmk_select_stream(0);
+      if (!rc) rc = ndsmk_stream_fence(1, 0);
+    }
+    if (!rc) rc = ndsmk_d2h(back.data(), dst, n * sizeof(double));
+    if (!rc && std::memcmp(back.data(), h.data(), n * sizeof(double)) != 0)
+      rc = ndsm::fail(NDSMK_ENCCL, pass ? "self send/recv on the communication stream returned other bytes"
+                                        : "self send/recv on the main stream returned other bytes", __FILE__, __LINE__);
+  }
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  if (rc) return rc;
+  double ms[2] = {3.5 + g_d.rank, 0.25};
+  rc = ndsmk_dist_allreduce_max_sum(ms);
+  if (rc) return rc;
+  if (ms[0] != 3.5 + (g_d.size - 1) || ms[1] != 0.25 * g_d.size)
+    return ndsm::fail(NDSMK_ENCCL, "2-value all-reduce returned a wrong (max, sum)", __FILE__, __LINE__);
   return 0;
 }
 

@@ -212,6 +212,11 @@ struct MScratch {
   double *h_pin = nullptr;
 };
 MScratch g_m;
+void mscratch_release() {
+  if (g_m.d_part) (void)hipFree(g_m.d_part);
+  if (g_m.h_pin) (void)hipHostFree(g_m.h_pin);
+  g_m = MScratch();
+}
 
 constexpr int kTX = 132, kTY = 15, kNT = 1024;
 
@@ -245,6 +250,7 @@ extern "C" int ndsmk_update_residual_f32(const ndsmk_grid *gp, const double *u, 
   pl.nzc = (nzo + zc - 1) / zc;
   pl.nwork = tiles * pl.nzc;
   const int nblk = ((pl.nwork + 7) / 8) * 8;
+  ndsm::at_reset(mscratch_release);
   if ((size_t)nblk > g_m.cap) {
     if (g_m.d_part) (void)hipFree(g_m.d_part);
     g_m.d_part = nullptr;

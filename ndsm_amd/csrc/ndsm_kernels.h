@@ -172,6 +172,9 @@ int ndsmk_relax_f32(const ndsmk_grid *g, float *e, float *ealt, const float *r, 
 int ndsmk_restrict_f32(const ndsmk_xfer *x, const float *r_f, double *rhs_c, double *u_c);
 int ndsmk_prolong_add_f32(const ndsmk_xfer *x, const double *u_c, float *e_f);
 
+/* tests / tuning: the five values of NDSM_FUSED_CFG (smooth_fused.hip) at run time */
+int ndsmk_debug_fused_cfg(int two, int one, int res, int work_items, int big);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,8 +21,14 @@ struct Scratch {
 };
 Scratch g_s;
 
+void scratch_release() {
+  if (g_s.d_part) (void)hipFree(g_s.d_part);
+  if (g_s.h_pin) (void)hipHostFree(g_s.h_pin);
+  g_s = Scratch();
+}
 int ensure_scratch() {
   if (g_s.d_part) return 0;
+  ndsm::at_reset(scratch_release);
   NDSM_HIP(hipMalloc((void **)&g_s.d_part, sizeof(double) * (2 * kRedMaxBlocks + 8)));
   NDSM_HIP(hipHostMalloc((void **)&g_s.h_pin, sizeof(double) * 8, hipHostMallocDefault));
   return 0;

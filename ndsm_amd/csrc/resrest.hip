@@ -291,12 +291,10 @@ extern "C" int ndsmk_residual_restrict(const ndsmk_grid *gp, const ndsmk_xfer *x
   const int nblk = ((a.nwork + 7) / 8) * 8;
   constexpr size_t lds_bytes = sizeof(double) * 2 * (2 * CI + 8) * (2 * CJ + 6);
   auto kfn = resrest_k<CI, CJ>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int attr_epoch = 0;
+  if (ndsm::first_in_epoch(attr_epoch))
     NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds_bytes));
-    attr_set = true;
-  }
   hipLaunchKernelGGL(kfn, dim3(nblk), dim3(CI * CJ), lds_bytes, ndsm::stream(), u, rhs, rhs_c, u_c, a);
   NDSM_LAUNCH_CHECK();
   return 0;

@@ -297,8 +297,8 @@ static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
   // coarse planes per chunk: one workgroup per CU at a time (LDS), a chunk of kc coarse planes
   // walks ~2 kc + 3 fine planes: minimise (rounds of workgroups) x (planes walked); the chunk's
   // z tables must fit their LDS arrays (kc <= kKCMax)
-  static int occ = 0;
-  if (!occ) {
+  static int occ = 0, occ_epoch = 0;
+  if (ndsm::first_in_epoch(occ_epoch)) {
     int o = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, restrict_stream_k<TF, kCI, kCJ, kMT, kKCMax>, kCI * kCJ,
                                                      sizeof(double) * 2 * (2 * kCI + 6) * (2 * kCJ + 5)) != hipSuccess || o < 1)
@@ -326,12 +326,10 @@ static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
   const int nblk = ((a.nwork + 7) / 8) * 8;
   constexpr size_t lds_bytes = sizeof(double) * 2 * (2 * kCI + 6) * (2 * kCJ + 5);
   auto kfn = restrict_stream_k<TF, kCI, kCJ, kMT, kKCMax>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int attr_epoch = 0;
+  if (ndsm::first_in_epoch(attr_epoch))
     NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds_bytes));
-    attr_set = true;
-  }
   hipLaunchKernelGGL(kfn, dim3(nblk), dim3(kCI * kCJ), lds_bytes, stream(), r_f, rhs_c, u_c, a);
   NDSM_LAUNCH_CHECK();
   return 0;

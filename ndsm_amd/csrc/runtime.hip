@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -23,6 +24,24 @@ struct Runtime {
 
 Runtime g_rt;
 std::mutex g_mu;
+int g_epoch = 0;                       // see common.hpp
+std::vector<void (*)()> g_reset_hooks;
+
+// the runtime is going away (shutdown or re-target): drain, let every translation unit drop what it
+// holds on this device, then destroy streams and events
+void tear_down() {
+  (void)hipStreamSynchronize(g_rt.stream);
+  (void)hipStreamSynchronize(g_rt.comm);
+  std::vector<void (*)()> hooks;
+  hooks.swap(g_reset_hooks);
+  for (auto fn : hooks) fn();
+  (void)hipStreamDestroy(g_rt.stream);
+  (void)hipStreamDestroy(g_rt.comm);
+  (void)hipEventDestroy(g_rt.evx);
+  (void)hipEventDestroy(g_rt.ev0);
+  (void)hipEventDestroy(g_rt.ev1);
+  g_rt.up = false;
+}
 
 }  // namespace
 
@@ -31,6 +50,12 @@ namespace ndsm {
 hipStream_t stream() { return g_rt.on_comm ? g_rt.comm : g_rt.stream; }
 bool ready() { return g_rt.up; }
 int cu_count() { return g_rt.ncu > 0 ? g_rt.ncu : 256; }
+int epoch() { return g_epoch; }
+void at_reset(void (*fn)()) {
+  for (auto f : g_reset_hooks)
+    if (f == fn) return;
+  g_reset_hooks.push_back(fn);
+}
 
 int fail(int code, const char *what, const char *file, int line) {
   const char *base = std::strrchr(file, '/');
@@ -68,14 +93,7 @@ int ndsmk_init(int device) {
     device = lr ? std::atoi(lr) % n : 0;
   }
   NDSM_CHECK_ARG(device < n);
-  if (g_rt.up) {  // re-target: drop the old stream
-    (void)hipStreamDestroy(g_rt.stream);
-    (void)hipStreamDestroy(g_rt.comm);
-    (void)hipEventDestroy(g_rt.evx);
-    (void)hipEventDestroy(g_rt.ev0);
-    (void)hipEventDestroy(g_rt.ev1);
-    g_rt.up = false;
-  }
+  if (g_rt.up) tear_down();  // re-target: everything bound to the old device goes (scratch, RCCL communicator, streams)
   NDSM_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   NDSM_HIP(hipGetDeviceProperties(&prop, device));
@@ -93,6 +111,7 @@ int ndsmk_init(int device) {
   NDSM_HIP(hipEventCreate(&g_rt.ev1));
   g_rt.device = device;
   g_rt.ncu = prop.multiProcessorCount;
+  ++g_epoch;
   g_rt.up = true;
   return 0;
 }
@@ -100,13 +119,7 @@ int ndsmk_init(int device) {
 int ndsmk_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_rt.up) return 0;
-  (void)hipStreamSynchronize(g_rt.stream);
-  (void)hipStreamSynchronize(g_rt.comm);
-  (void)hipStreamDestroy(g_rt.stream);
-  (void)hipStreamDestroy(g_rt.comm);
-  (void)hipEventDestroy(g_rt.evx);
-  (void)hipEventDestroy(g_rt.ev0);
-  (void)hipEventDestroy(g_rt.ev1);
+  tear_down();
   g_rt = Runtime();
   return 0;
 }
@@ -132,6 +145,7 @@ int ndsmk_alloc(void **p, size_t bytes) {
 int ndsmk_free(void *p) {
   if (!p) return 0;
   NDSM_REQUIRE_READY();
+  NDSM_HIP(hipStreamSynchronize(g_rt.comm));   // halo copies / RCCL calls may still read it
   NDSM_HIP(hipStreamSynchronize(g_rt.stream));
   NDSM_HIP(hipFree(p));
   return 0;

@@ -291,12 +291,10 @@ static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double 
     if (prol_pending) {
       if (int rc = ndsmk_prolong_add(px, uc, bufs[0])) return rc;
     }
-    static bool attr = false;
-    if (!attr) {
+    static int attr_epoch = 0;
+    if (ndsm::first_in_epoch(attr_epoch))
       NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rbgs2_medium), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    kMed2D * (int)sizeof(double)));
-      attr = true;
-    }
     hipLaunchKernelGGL(rbgs2_medium, dim3(1), dim3(1024), (size_t)npts * sizeof(double), s, bufs[0], rhs, g, nsweeps);
     NDSM_LAUNCH_CHECK();
     return 0;

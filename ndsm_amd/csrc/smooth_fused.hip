@@ -791,7 +791,13 @@ struct MetScratch {
 };
 MetScratch g_met;
 bool g_met_acc = false;  // the next MET launch adds to the folded pair instead of replacing it
+void met_release() {
+  if (g_met.d) (void)hipFree(g_met.d);
+  g_met = MetScratch();
+  g_met_acc = false;
+}
 int met_scratch(size_t nblk, double **part, double **out2) {
+  ndsm::at_reset(met_release);
   if (nblk > g_met.cap) {
     double *nd = nullptr;
     NDSM_HIP(hipMalloc((void **)&nd, sizeof(double) * (2 * nblk + 2)));
@@ -825,12 +831,12 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
   const int tiles = pl.ntx * pl.nty;
   const int nzo = g.zown1 - g.zown0;  // owned planes
   const size_t lds_bytes = sizeof(T) * NST * TXH * TYH + (MODE == 3 ? 2 * sizeof(double) * (TXH / 2 + 3) * (TYH / 2 + 3) : 0);
-  static bool attr_set[2] = {false, false};
+  static int attr_epoch[2] = {0, 0};   // per instantiation and device epoch (ndsmk_init may re-target)
   static int wgs_per_cu[2] = {1, 1};
   const int v = rhs ? 0 : 1;
   const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1, ODD>)
                          : reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1, ODD>);
-  if (!attr_set[v]) {
+  if (ndsm::first_in_epoch(attr_epoch[v])) {
     NDSM_HIP(hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int occ = 1;
     if (rhs)
@@ -840,7 +846,6 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
       NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1, ODD>, NT,
                                                             lds_bytes));
     wgs_per_cu[v] = occ > 0 ? occ : 1;
-    attr_set[v] = true;
   }
   // z chunks.  A workgroup walks its chunk plus NST warm-up planes on either side, and
   // the chip runs ncu * wgs_per_cu workgroups at a time: pick the chunk count that
@@ -897,14 +902,17 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
 
 namespace ndsm {
 
-// Development knob: NDSM_FUSED_CFG=<two-sweep cfg>,<one-sweep cfg>,<sweep+residual cfg> picks
-// tile configurations (default 0,0,0; scripts/tune_smoother.py).
+// Development knob: NDSM_FUSED_CFG=<two-sweep cfg>,<one-sweep cfg>,<sweep+residual cfg>,<work items>,<big>
+// picks tile configurations (default 0,0,0,0,-1; scripts/tune_smoother.py).  <big>: -1 = by level size
+// (>= 64 M points), 0 / 1 = never / always take the large-level tiles - the parity tests run them on
+// oracle-sized grids that way (ndsmk_debug_fused_cfg sets the same five values at run time).
+static int g_fcfg[5] = {-1, 0, 0, 0, -1};
 static const int *fused_cfg() {
-  static int cfg[4] = {-1, 0, 0, 0};
+  int *cfg = g_fcfg;
   if (cfg[0] < 0) {
     cfg[0] = 0;
     const char *e = std::getenv("NDSM_FUSED_CFG");
-    for (int i = 0; e && i < 4; ++i) {
+    for (int i = 0; e && i < 5; ++i) {
       cfg[i] = std::atoi(e);
       e = std::strchr(e, ',');
       if (e) ++e;
@@ -934,7 +942,7 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   int rc;
   const int *cfg = fused_cfg();
   const int tgt = cfg[3] > 0 ? cfg[3] : 0;  // > 0: that many work items instead of launch_cfg's own choice
-  const bool big = npts >= (int64_t)64 * 1024 * 1024;
+  const bool big = cfg[4] < 0 ? npts >= (int64_t)64 * 1024 * 1024 : cfg[4] != 0;
   // A z-slab carries zown0 ghost planes below and n[2] - zown1 above its owned range; the caller
   // (ndsmh_world) has exchanged as many as the pass it asks for consumes: 2 per sweep, +1 for
   // the residual stage.
@@ -1071,3 +1079,13 @@ int launch_rbgs3_fused_f32(const ndsmk_grid &g, const float *u, float *uout, con
 }
 
 }  // namespace ndsm
+
+// tests / tuning: the five values of NDSM_FUSED_CFG, set at run time
+extern "C" int ndsmk_debug_fused_cfg(int two, int one, int res, int work_items, int big) {
+  ndsm::g_fcfg[0] = two < 0 ? 0 : two;
+  ndsm::g_fcfg[1] = one;
+  ndsm::g_fcfg[2] = res;
+  ndsm::g_fcfg[3] = work_items;
+  ndsm::g_fcfg[4] = big;
+  return 0;
+}

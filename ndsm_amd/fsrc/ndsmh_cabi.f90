@@ -41,6 +41,20 @@ module ndsmh_cabi
       import :: c_int
       integer(c_int) :: rc
     end function
+    function ndsmk_dist_info(rank, nranks) bind(c, name="ndsmk_dist_info") result(rc)
+      import :: c_int
+      integer(c_int), intent(out) :: rank, nranks
+      integer(c_int) :: rc
+    end function
+    function ndsmk_dist_selftest(nelem) bind(c, name="ndsmk_dist_selftest") result(rc)
+      import :: c_int
+      integer(c_int), value :: nelem
+      integer(c_int) :: rc
+    end function
+    function ndsmk_shutdown() bind(c, name="ndsmk_shutdown") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
   end interface
 
   interface
@@ -273,6 +287,14 @@ contains
     integer(c_int), value :: device
     integer(c_int) :: rc
     rc = ndsmk_init(device)
+  end function
+
+  ! releases everything the library holds on the device outside the caller's handles (streams, events,
+  ! metric scratch, the cached vector-potential hierarchy, a live RCCL communicator); destroy solver /
+  ! world handles first.  ndsm_hip_init (or any solve) brings the runtime up again, on any device.
+  function ndsm_hip_shutdown() bind(c, name="ndsm_hip_shutdown") result(rc)
+    integer(c_int) :: rc
+    rc = ndsmk_shutdown()
   end function
 
   subroutine ndsm_hip_last_error(buf, n) bind(c, name="ndsm_hip_last_error")
@@ -581,6 +603,23 @@ contains
     rc = ndsmk_dist_finalize()
   end function
 
+  ! rank and size as the RCCL communicator reports them (ncclCommUserRank / ncclCommCount);
+  ! nranks = 0: no communicator is up
+  function ndsm_hip_dist_info(rank, nranks) bind(c, name="ndsm_hip_dist_info") result(rc)
+    integer(c_int), intent(out) :: rank, nranks
+    integer(c_int) :: rc
+    rc = ndsmk_dist_info(rank, nranks)
+  end function
+
+  ! transport self-test on the live communicator (collective): self send/recv of nelem doubles through
+  ! the grouped ncclSend/ncclRecv pair of a halo exchange, on the main and on the communication stream,
+  ! and the 2-value all-reduce; 0 = every byte arrived
+  function ndsm_hip_dist_selftest(nelem) bind(c, name="ndsm_hip_dist_selftest") result(rc)
+    integer(c_int), value :: nelem
+    integer(c_int) :: rc
+    rc = ndsmk_dist_selftest(nelem)
+  end function
+
   ! The slab plan every rank derives (pure host arithmetic, no GPU needed).
   ! out(12, nranks): rank, z0, z1, g, nloc, k0, ck0, ck1, pk0, pk1, cb0, cb1
   function ndsm_hip_slab_plan(nshape, x, y, z, ngrids, nranks, out) bind(c, name="ndsm_hip_slab_plan") result(rc)
@@ -754,6 +793,21 @@ contains
       end function
     end interface
     rc = ndsmk_bound_libs(buf, len)
+  end function
+
+  ! development hook (tests, tuning): tile configuration of the fused smoother, the five values of
+  ! NDSM_FUSED_CFG (smooth_fused.hip) - big = 1 runs the tiles of >= 64 M-point levels on any level
+  function ndsm_hip_debug_fused_cfg(two, one, res, work_items, big) bind(c, name="ndsm_hip_debug_fused_cfg") result(rc)
+    integer(c_int), value :: two, one, res, work_items, big
+    integer(c_int) :: rc
+    interface
+      function ndsmk_debug_fused_cfg(two, one, res, work_items, big) bind(c, name="ndsmk_debug_fused_cfg") result(rc)
+        import :: c_int
+        integer(c_int), value :: two, one, res, work_items, big
+        integer(c_int) :: rc
+      end function
+    end interface
+    rc = ndsmk_debug_fused_cfg(two, one, res, work_items, big)
   end function
 
   function ndsm_hip_world_vcycle(handle, ncycles) bind(c, name="ndsm_hip_world_vcycle") result(rc)

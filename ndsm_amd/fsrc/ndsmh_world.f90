@@ -358,7 +358,7 @@ contains
   function exchange(w, which, depth) result(rc)
     type(mg_world), intent(inout) :: w
     integer, intent(in) :: which, depth
-    integer(c_int) :: rc
+    integer(c_int) :: rc, rc2
     integer :: i, r, g, nown
     integer(ik) :: cnt
     integer(c_size_t) :: pl, nb
@@ -378,34 +378,38 @@ contains
         if (r < w%nranks - 1) then      ! upper neighbour r+1: my last owned planes -> its lower ghosts
           if (w%rccl) then
             rc = ndsmk_dist_send(dptr_offset(me, int(g + nown - depth, c_size_t) * pl * R8), nb, int(r + 1, c_int))
-            if (rc /= 0) return
+            if (rc /= 0) goto 800
             rc = ndsmk_dist_recv(dptr_offset(me, int(g + nown, c_size_t) * pl * R8), nb, int(r + 1, c_int))
-            if (rc /= 0) return
+            if (rc /= 0) goto 800
           else
             nbr = mg_level_ptr(w%loc(i + 1), 1, which, cnt)
             rc = ndsmk_d2d(dptr_offset(nbr, int(w%loc(i + 1)%sl%g - depth, c_size_t) * pl * R8), &
                            dptr_offset(me, int(g + nown - depth, c_size_t) * pl * R8), nb * R8)
-            if (rc /= 0) return
+            if (rc /= 0) goto 800
             rc = ndsmk_d2d(dptr_offset(me, int(g + nown, c_size_t) * pl * R8), &
                            dptr_offset(nbr, int(w%loc(i + 1)%sl%g, c_size_t) * pl * R8), nb * R8)
-            if (rc /= 0) return
+            if (rc /= 0) goto 800
           end if
         end if
         if (r > 0 .and. w%rccl) then    ! lower neighbour r-1 (loop-back: done from its side)
           rc = ndsmk_dist_send(dptr_offset(me, int(g, c_size_t) * pl * R8), nb, int(r - 1, c_int))
-          if (rc /= 0) return
+          if (rc /= 0) goto 800
           rc = ndsmk_dist_recv(dptr_offset(me, int(g - depth, c_size_t) * pl * R8), nb, int(r - 1, c_int))
-          if (rc /= 0) return
+          if (rc /= 0) goto 800
         end if
       end associate
     end do
-    if (w%rccl) rc = ndsmk_dist_group_end()
+800 continue   ! errors inside the group land here too: an open ncclGroupStart must be closed
+    if (w%rccl) then
+      rc2 = ndsmk_dist_group_end()
+      if (rc == 0) rc = rc2
+    end if
   end function
 
   ! coarse planes computed by every rank -> rhs(2) on rank 0 ; u(2) = 0 there
   function gather_coarse(w) result(rc)
     type(mg_world), intent(inout) :: w
-    integer(c_int) :: rc
+    integer(c_int) :: rc, rc2
     integer :: i, r
     integer(c_size_t) :: pl2
     integer(ik) :: cnt
@@ -434,18 +438,21 @@ contains
                              dptr_offset(w%loc(r + 1)%cbuf, int(w%plan(r)%ck0 - w%plan(r)%cb0, c_size_t) * pl2 * R8), &
                              int(w%plan(r)%ck1 - w%plan(r)%ck0, c_size_t) * pl2 * R8)
             end if
-            if (rc /= 0) return
+            if (rc /= 0) goto 800
           end do
         else if (w%rccl .and. s%sl%ck1 > s%sl%ck0) then
           rc = ndsmk_dist_send(dptr_offset(s%cbuf, int(s%sl%ck0 - s%sl%cb0, c_size_t) * pl2 * R8), &
                                int(s%sl%ck1 - s%sl%ck0, c_size_t) * pl2, 0_c_int)
-          if (rc /= 0) return
+          if (rc /= 0) goto 800
         end if
       end associate
     end do
+800 continue   ! errors inside the group land here too: an open ncclGroupStart must be closed
     if (w%rccl) then
-      rc = ndsmk_dist_group_end(); if (rc /= 0) return
+      rc2 = ndsmk_dist_group_end()
+      if (rc == 0) rc = rc2
     end if
+    if (rc /= 0) return
     do i = 1, w%nlocal
       if (w%loc(i)%sl%rank == 0) then
         dst = mg_level_ptr(w%loc(i), 2, MG_BUF_U, cnt)
@@ -457,7 +464,7 @@ contains
   ! u(2) planes [pk0, pk1) of rank 0 -> every rank's cbuf
   function scatter_coarse(w) result(rc)
     type(mg_world), intent(inout) :: w
-    integer(c_int) :: rc
+    integer(c_int) :: rc, rc2
     integer :: i, r
     integer(c_size_t) :: pl2
     integer(ik) :: cnt
@@ -485,16 +492,20 @@ contains
                              dptr_offset(src, int(w%plan(r)%pk0, c_size_t) * pl2 * R8), &
                              int(w%plan(r)%pk1 - w%plan(r)%pk0, c_size_t) * pl2 * R8)
             end if
-            if (rc /= 0) return
+            if (rc /= 0) goto 800
           end do
         else if (w%rccl) then
           rc = ndsmk_dist_recv(dptr_offset(s%cbuf, int(s%sl%pk0 - s%sl%cb0, c_size_t) * pl2 * R8), &
                                int(s%sl%pk1 - s%sl%pk0, c_size_t) * pl2, 0_c_int)
-          if (rc /= 0) return
+          if (rc /= 0) goto 800
         end if
       end associate
     end do
-    if (w%rccl) rc = ndsmk_dist_group_end()
+800 continue   ! errors inside the group land here too: an open ncclGroupStart must be closed
+    if (w%rccl) then
+      rc2 = ndsmk_dist_group_end()
+      if (rc == 0) rc = rc2
+    end if
   end function
 
   ! make at least `depth` ghost planes of u(1) per side current
@@ -843,7 +854,7 @@ contains
     type(mg_world), intent(inout) :: w
     type(c_ptr), intent(in) :: p(:)
     integer, intent(in) :: depth
-    integer(c_int) :: rc
+    integer(c_int) :: rc, rc2
     integer :: i, r, g, nown
     integer(c_size_t) :: pl, nb
     integer(c_size_t), parameter :: R4 = 4_c_size_t
@@ -860,27 +871,31 @@ contains
         if (r < w%nranks - 1) then
           if (w%rccl) then
             rc = ndsmk_dist_send_bytes(dptr_offset(p(i), int(g + nown - depth, c_size_t) * pl), nb, int(r + 1, c_int))
-            if (rc /= 0) return
+            if (rc /= 0) goto 800
             rc = ndsmk_dist_recv_bytes(dptr_offset(p(i), int(g + nown, c_size_t) * pl), nb, int(r + 1, c_int))
-            if (rc /= 0) return
+            if (rc /= 0) goto 800
           else
             rc = ndsmk_d2d(dptr_offset(p(i + 1), int(w%loc(i + 1)%sl%g - depth, c_size_t) * pl), &
                            dptr_offset(p(i), int(g + nown - depth, c_size_t) * pl), nb)
-            if (rc /= 0) return
+            if (rc /= 0) goto 800
             rc = ndsmk_d2d(dptr_offset(p(i), int(g + nown, c_size_t) * pl), &
                            dptr_offset(p(i + 1), int(w%loc(i + 1)%sl%g, c_size_t) * pl), nb)
-            if (rc /= 0) return
+            if (rc /= 0) goto 800
           end if
         end if
         if (r > 0 .and. w%rccl) then
           rc = ndsmk_dist_send_bytes(dptr_offset(p(i), int(g, c_size_t) * pl), nb, int(r - 1, c_int))
-          if (rc /= 0) return
+          if (rc /= 0) goto 800
           rc = ndsmk_dist_recv_bytes(dptr_offset(p(i), int(g - depth, c_size_t) * pl), nb, int(r - 1, c_int))
-          if (rc /= 0) return
+          if (rc /= 0) goto 800
         end if
       end associate
     end do
-    if (w%rccl) rc = ndsmk_dist_group_end()
+800 continue   ! errors inside the group land here too: an open ncclGroupStart must be closed
+    if (w%rccl) then
+      rc2 = ndsmk_dist_group_end()
+      if (rc == 0) rc = rc2
+    end if
   end function
 
   function need_e_ghosts(w, depth) result(rc)

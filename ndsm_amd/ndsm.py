@@ -38,7 +38,11 @@ def vector_potential(x, y, z, b, niterex_max=10000, ncycles_max=1024, ex_tol=1e-
     fp64 residual + fp32 correction V-cycle (option slot get_iopt_prec(), BASELINE config[4]).
 
     Returns (ierr, A, B) with A, B shaped (3,nz,ny,nx); ierr != 0 flags a V-cycle
-    iteration that did not reach vc_tol (codes >= 9001: device/runtime error).
+    iteration that did not reach vc_tol.  Device / runtime failures (no MI355X visible, out of
+    HBM, ...) come back the way the reference reports everything - as the return code, here
+    >= 9001, with A left at zero and the text on stderr and in `_lib.last_error()` - so that
+    callers written against the reference's (ierr, A, B) contract keep working; the additive
+    entry points of this package (MGSolver, poisson_solve, vector_potential_slab) raise instead.
     """
     if libpath is None:
         if libname is None:
@@ -53,7 +57,11 @@ def vector_potential(x, y, z, b, niterex_max=10000, ncycles_max=1024, ex_tol=1e-
     if not os.path.exists(libpath):
         raise NdsmHipError(f"{libpath} not found - build it with `make -C ndsm_amd`; there is no CPU fallback")
     try:
-        lib = ctypes.cdll.LoadLibrary(libpath)
+        # same dlopen mode as _lib.load_library: RTLD_DEEPBIND keeps the library's hip*/nccl* calls on the
+        # ROCm stack it was linked against even when PyTorch's bundled one is already in the process (the
+        # FIRST dlopen of an object fixes its mode for the life of the process, and this may be it).  A CDLL
+        # object of its own: the ndpointer prototypes set below stay private to this function.
+        lib = ctypes.CDLL(libpath, mode=os.RTLD_NOW | os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
     except OSError as exc:
         raise ValueError("Could not load library at " + libpath) from exc
 
@@ -80,6 +88,9 @@ def vector_potential(x, y, z, b, niterex_max=10000, ncycles_max=1024, ex_tol=1e-
     ioptc[slots["debug"]] = lib.get_iopt_true() if debug else lib.get_iopt_false()
     ioptc[slots["dumax"]] = lib.get_iopt_false() if mean else lib.get_iopt_true()
     if mixed_precision:
+        if not hasattr(lib, "get_iopt_prec"):
+            raise NdsmHipError(f"{libpath} has no mixed-precision option slot (get_iopt_prec): it is not libndsm_hip "
+                               "- the reference build only knows fp64")
         ioptc[lib.get_iopt_prec()] = int(mixed_precision)    # True/1: where level 1 is large; 2: wherever the fp32 kernels apply
 
     apot = np.zeros(b.size, dtype=np.float64)

@@ -235,6 +235,16 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
+  *count = reinterpret_cast<const Comm *>(comm)->n;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank) {
+  *rank = reinterpret_cast<const Comm *>(comm)->rank;
+  return ncclSuccess;
+}
+
 const char *ncclGetErrorString(ncclResult_t r) {
   switch (r) {
     case ncclSuccess: return "no error";

@@ -182,5 +182,6 @@ def test_bench_two_ranks_rehearsal(hip):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert "z-slabs" in out["config"]["parallelism"], out["config"]
-    assert out["slab_check"].startswith("bit-identical"), out["slab_check"]
+    assert out["slab_check"].startswith("bit-identical") and "MISMATCH" not in out["slab_check"], out["slab_check"]
+    assert out["slab_mode"] is True and out["rccl_ranks"] == 2
     assert "fake_rccl" in out["rocm_stack"]["rccl"]

@@ -1006,3 +1006,174 @@ def test_baseline_config2_full_pipeline_512(hip):
     eb = np.sqrt(((b1 - B) ** 2).sum(axis=0)).max()
     assert ea < 2.0 * h * h and eb < 60.0 * h * h, (ea / h ** 2, eb / h ** 2)
     assert np.abs(B[2, 0] - b1[2, 0]).max() < 60.0 * h * h        # Bz on the lower z face
+
+
+# ---------------------------------------------------------------------------
+# The tile configurations of the benchmarked grids (>= 64 M points: `big` in smooth_fused.hip's
+# launch_fused_t - <2,136,30,1024> under its level-1 symbol, <1,132,31,1024> plain and with the metric)
+# against an INDEPENDENT implementation: forced onto oracle-sized grids, and at 512^3 itself.
+# ---------------------------------------------------------------------------
+@pytest.fixture()
+def big_tiles(hip):
+    L = hip.load_library()
+    L.ndsm_hip_debug_fused_cfg(0, 0, 0, 0, 1)
+    yield
+    L.ndsm_hip_debug_fused_cfg(0, 0, 0, 0, -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns", ([256, 192, 160], [200, 100, 120], [161, 120, 115]), ids=_tag)
+def test_large_level_tiles_forced_vs_oracle(hip, port, big_tiles, ns):
+    """the >= 64 M-point tile choices on grids the oracle handles in seconds: five sweeps (2 + 2 + 1: the
+    level-1 two-sweep symbol and the big one-sweep tile), general and declared-zero rhs, then three
+    solve-loop cycles (sweep + metric on the big one-sweep tile) - solution bits and du history"""
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
+    zero = np.zeros(shp)
+    bcs = "NDDNDD"
+    S = hip.MGSolver(ns, mesh, bcs)
+    for lap in (False, True):
+        S.upload(1, hip.BUF_U, u)
+        if lap:
+            S.zero_rhs()
+        else:
+            S.upload(1, hip.BUF_RHS, rhs)
+        S.op(hip.OP_RELAX_FUSED, 1, 5)
+        want = u
+        for _ in range(5):
+            want = port.relax3d(want, zero if lap else rhs, mesh, bcs)
+        assert np.array_equal(S.download(1, hip.BUF_U), want), lap
+        S.upload(1, hip.BUF_U, u)
+        S.op(hip.OP_RELAX_FUSED, 1, 1)                    # the one-sweep tile alone
+        assert np.array_equal(S.download(1, hip.BUF_U), port.relax3d(u, zero if lap else rhs, mesh, bcs)), lap
+    S.close()
+    for lap in (True, False):
+        r = zero if lap else rhs * 10.0
+        ie2, u2, du2, h2, nc2, _sw = port.solve_bvp(u.copy(), r, mesh, bcs, ms=5, nmax=3, hist_len=8)
+        S = hip.MGSolver(ns, mesh, bcs, ms=5)
+        if lap:
+            S.zero_rhs()
+        else:
+            S.upload(1, hip.BUF_RHS, r)
+        S.upload(1, hip.BUF_U, u)
+        ie, du, nc, h = S.solve(vc_tol=1e-10, nmax=3, hist_len=8)
+        got = S.download(1, hip.BUF_U)
+        S.close()
+        assert nc == nc2 == 3 and list(h) == list(h2[:3]), (lap, list(h), list(h2[:3]))
+        assert np.array_equal(got, u2), lap
+
+
+@pytest.mark.gpu
+def test_benchmarked_512_kernels_vs_oracle(hip, port):
+    """BASELINE config[2]'s grid itself (512^3 = 134 M points, where launch_fused_t takes the big tiles by
+    its own rule): the launches bench.py times against the ORACLE - five fused sweeps with a general rhs
+    (two-sweep level-1 launch x2 + big one-sweep tile), the residual, and - the timed step itself - one
+    pass of the solve loop on the Ax Laplace problem (two-sweep Laplace launches, sweep + residual,
+    streamed restriction, correction folded into the post-smoothing, sweep + metric on the big tile,
+    levels 2-8): du and solution bits."""
+    import bench
+    n = 512
+    ns = [n, n, n]
+    shp = (n, n, n)
+    bcs = "NDDNDD"
+    mesh, u0 = bench.boundary_problem(n)
+    rhs = rand_field(shp, 2113)
+    u = rand_field(shp, 2112)
+    S = hip.MGSolver(ns, mesh, bcs)
+    S.upload(1, hip.BUF_U, u)
+    S.upload(1, hip.BUF_RHS, rhs)
+    S.op(hip.OP_RELAX_FUSED, 1, 5)
+    S.op(hip.OP_RESIDUAL, 1)
+    got, gotr = S.download(1, hip.BUF_U), S.download(1, hip.BUF_R)
+    want = u
+    for _ in range(5):
+        want = port.relax3d(want, rhs, mesh, bcs, inplace=want is not u)
+    assert np.array_equal(got, want)
+    assert np.array_equal(gotr, port.residual3d(want, rhs, mesh, bcs))
+    del got, gotr, want, u, rhs
+    # the timed step: solve-loop pass on the Laplace problem
+    S.upload(1, hip.BUF_U, u0)
+    S.zero_rhs()
+    ie, du, nc, h = S.solve(vc_tol=0.0, nmax=1, hist_len=4)
+    got = S.download(1, hip.BUF_U)
+    S.close()
+    ie2, u2, du2, h2, nc2, _sw = port.solve_bvp(u0, np.zeros(shp), mesh, bcs, ms=5, vc_tol=0.0, nmax=1, hist_len=4)
+    assert nc == nc2 == 1 and list(h) == list(h2[:1]), (list(h), list(h2))
+    assert np.array_equal(got, u2)
+
+
+@pytest.mark.gpu
+def test_benchmarked_512_fused_vs_colour_kernels(hip):
+    """512^3, second independent check that needs no CPU time: the fused launches (big tiles) against the
+    thread-per-point colour passes + stand-alone residual and metric kernels (which the small-shape tests
+    pin to the oracle and the reference's golden vectors), general and zero rhs, 1 / 2 / 5 sweeps"""
+    n = 512
+    ns = [n, n, n]
+    shp = (n, n, n)
+    mesh = uniform_mesh(ns)
+    u, rhs = rand_field(shp, 5), rand_field(shp, 6)
+    for bcs in ("NDDNDD", "DDNDDN"):
+        S = hip.MGSolver(ns, mesh, bcs)
+        for lap in (False, True):
+            if lap:
+                S.zero_rhs()
+            else:
+                S.upload(1, hip.BUF_RHS, rhs)
+            for nsw in (1, 2, 5):
+                S.upload(1, hip.BUF_U, u)
+                S.op(hip.OP_RELAX_COLOR, 1, nsw)
+                S.op(hip.OP_RESIDUAL, 1)
+                uw, rw = S.download(1, hip.BUF_U), S.download(1, hip.BUF_R)
+                S.upload(1, hip.BUF_U, u)
+                S.op(hip.OP_RELAX_RES_FUSED, 1, nsw)
+                assert np.array_equal(S.download(1, hip.BUF_U), uw), (bcs, lap, nsw)
+                assert np.array_equal(S.download(1, hip.BUF_R), rw), (bcs, lap, nsw)
+                S.upload(1, hip.BUF_U, u)
+                S.op(hip.OP_RELAX_FUSED, 1, nsw)
+                assert np.array_equal(S.download(1, hip.BUF_U), uw), (bcs, lap, nsw)
+        S.close()
+
+
+@pytest.mark.gpu
+def test_baseline_config1_vs_oracle(hip, port):
+    """BASELINE config[1] against the oracle, not only through properties: 256^3 Poisson, ngrids = 6 -
+    the whole solve's du history, cycle count, coarse sweep count and solution bits"""
+    ns = [256, 256, 256]
+    mesh = uniform_mesh(ns)
+    us, rhs = manufactured_poisson(mesh, "NDDNDD")
+    ierr, u, du, hist, nc = hip.poisson_solve(np.zeros_like(us), rhs, mesh, "NDDNDD", ngrids=6, hist_len=64)
+    ierr2, u2, du2, hist2, nc2, _sw = port.solve_bvp(np.zeros_like(us), rhs, mesh, "NDDNDD", ngrids=6, hist_len=64)
+    assert ierr == ierr2 == 0 and nc == nc2
+    assert list(hist) == list(hist2[:nc2])
+    assert du == du2
+    assert np.array_equal(u, u2)
+
+
+@pytest.mark.gpu
+def test_full_size_config4_loopback_poisson(hip):
+    """BASELINE config[3] as written - a POISSON problem: 1024 x 1024 x 512 with a non-zero right-hand
+    side (the general-rhs slab kernels, stand-alone prolongation), 8 z-slabs in loop-back against the
+    single-domain solver: one V-cycle and the convergence metric, bit for bit."""
+    ns = [1024, 1024, 512]
+    dx = 1.0 / (ns[0] - 1)
+    mesh = [np.arange(n) * dx for n in ns]
+    rng = np.random.default_rng(13)
+    az, by, cx = rng.uniform(-1, 1, ns[2]), rng.uniform(-1, 1, ns[1]), rng.uniform(-1, 1, ns[0])
+    u = az[:, None, None] * by[None, :, None] + cx[None, None, :]
+    rhs = (by[None, :, None] * cx[None, None, :]) * az[:, None, None] * 50.0 + 1.0
+    W = hip.World(ns, mesh, "NDDNDD", 8)
+    W.upload(hip.BUF_U, u)
+    W.upload(hip.BUF_RHS, rhs)
+    ie, du_w, nc, hw = W.solve(vc_tol=0.0, nmax=1, hist_len=2)
+    b = W.download(hip.BUF_U)
+    W.close()
+    S = hip.MGSolver(ns, mesh, "NDDNDD")
+    S.upload(1, hip.BUF_U, u)
+    S.upload(1, hip.BUF_RHS, rhs)
+    del u, rhs
+    ie, du_s, nc, hs = S.solve(vc_tol=0.0, nmax=1, hist_len=2)
+    a = S.download(1, hip.BUF_U)
+    S.close()
+    assert list(hw) == list(hs) and du_w == du_s
+    assert np.array_equal(a, b)

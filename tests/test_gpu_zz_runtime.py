@@ -1,0 +1,96 @@
+"""GPU tests of the runtime layer that must run LAST in the session (the file name sorts behind the
+parity tests): bring-up of the REAL RCCL library on one rank, and shutdown / re-initialisation of the
+device runtime with everything the library caches on the device."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from golden_inputs import analytic_case, rand_field, uniform_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ndsm_amd
+    from ndsm_amd import _lib
+    L = ndsm_amd.load_library()
+    rc = L.ndsm_hip_init(-1)
+    assert rc == 0, _lib.last_error(L)
+    return _lib
+
+
+def test_real_rccl_one_rank_bringup(hip):
+    """the product library against the REAL librccl (the multi-rank tests use a shared-memory stand-in,
+    two ranks on one GPU being refused by RCCL): unique id -> ncclCommInitRank(1 rank) -> the library's
+    own grouped ncclSend/ncclRecv pair to itself on the main and on the communication stream -> the
+    2-value all-reduce -> a World on that communicator -> ncclCommDestroy"""
+    L = hip.load_library()
+    libs = hip.bound_libs(L)
+    assert "/opt/rocm" in libs["rccl"] and "librccl.so" in libs["rccl"], libs
+    assert "/opt/rocm" in libs["hip"], libs
+    assert hip.dist_info(L) == (0, 0)
+    uid = hip.dist_unique_id(L)
+    hip.dist_init(0, 1, uid, L)
+    try:
+        assert hip.dist_info(L) == (0, 1)          # ncclCommUserRank / ncclCommCount of the live communicator
+        for nelem in (2, 4096, 1 << 20):            # 8 MiB: the size of one 1024^2 halo plane
+            rc = L.ndsm_hip_dist_selftest(nelem)
+            assert rc == 0, hip.last_error(L)
+        ns = [64, 48, 40]
+        mesh = uniform_mesh(ns)
+        shp = tuple(ns[::-1])
+        u, rhs = rand_field(shp, 1), rand_field(shp, 2)
+        W = hip.World(ns, mesh, "NDDNDD", 1, 0)
+        W.upload(hip.BUF_U, u)
+        W.upload(hip.BUF_RHS, rhs)
+        iw, duw, ncw, hw = W.solve(vc_tol=1e-10, nmax=3, hist_len=4)
+        got = W.download(hip.BUF_U)
+        W.close()
+        S = hip.MGSolver(ns, mesh, "NDDNDD")
+        S.upload(1, hip.BUF_U, u)
+        S.upload(1, hip.BUF_RHS, rhs)
+        i_s, dus, ncs, hs = S.solve(vc_tol=1e-10, nmax=3, hist_len=4)
+        want = S.download(1, hip.BUF_U)
+        S.close()
+        assert list(hw) == list(hs) and np.array_equal(got, want)
+    finally:
+        hip.dist_finalize(L)
+    assert hip.dist_info(L) == (0, 0)
+
+
+def test_shutdown_and_reinit(hip):
+    """ndsm_hip_shutdown drops streams, scratch and caches; the next call brings the runtime up again and
+    re-issues the per-kernel attributes (dynamic-LDS sizes of the fused smoother / streamed restriction):
+    a solve that uses every large-level launch gives the same bits before and after"""
+    import ndsm_amd
+    L = hip.load_library()
+    ns = [161, 120, 115]
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u0 = rand_field(shp, 21)
+
+    def run():
+        S = hip.MGSolver(ns, mesh, "NDDNDD", ms=5)
+        S.zero_rhs()
+        S.upload(1, hip.BUF_U, u0)
+        ie, du, nc, h = S.solve(vc_tol=1e-10, nmax=3, hist_len=8)
+        out = S.download(1, hip.BUF_U)
+        S.close()
+        return list(h), out
+
+    x, y, z, _A1, b1 = analytic_case(22)
+    h1, a1 = run()
+    _i, A1, B1 = ndsm_amd.vector_potential(x, y, z, b1.copy())
+    assert L.ndsm_hip_shutdown() == 0
+    assert L.ndsm_hip_shutdown() == 0           # idempotent
+    assert L.ndsm_hip_sync() == 9001            # nothing is up: an error code, not a crash
+    assert L.ndsm_hip_init(0) == 0
+    h2, a2 = run()
+    assert h1 == h2 and np.array_equal(a1, a2)
+    assert L.ndsm_hip_shutdown() == 0
+    _i, A2, B2 = ndsm_amd.vector_potential(x, y, z, b1.copy())     # re-initialises by itself
+    assert np.array_equal(A1, A2) and np.array_equal(B1, B2)
+    h3, a3 = run()
+    assert h1 == h3 and np.array_equal(a1, a3)
