@@ -132,6 +132,32 @@ int ndsm_hip_mg_solve(void *handle, double vc_tol, int nmax, double *du_last, in
                       double *hist, int hist_len);
 int ndsm_hip_mg_info(void *handle, int64_t *exact_sweeps, int64_t *unconverged_coarse_solves);
 
+/* device memory on the library's GPU for callers without a HIP binding of their own (blocking copies on
+ * the library stream); pointers from the caller's own hipMalloc work just as well */
+int ndsm_hip_device_alloc(size_t bytes, void **p);
+int ndsm_hip_device_free(void *p);
+int ndsm_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
+int ndsm_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
+
+/* ---- persistent vector-potential solver ----
+ * The reference rebuilds its grid hierarchy per component and per call (ndsm_vector_potential.f90:652-689,
+ * ndsm_multigrid_core.f90:165-329).  Here everything that depends on the grid alone - the 3-D hierarchy and
+ * its transfer tables, the three 2-D face hierarchies, device arrays for A, B and the six faces - lives in a
+ * handle; time-series callers solve again and again on the same mesh.  (ndsm_vector_solve keeps ONE such
+ * context internally, keyed by shape, mesh and level cap: a second call on the same mesh skips the set-up
+ * without the caller changing anything.  ndsm_hip_shutdown drops it.)
+ *   nshape4 = [nx,ny,nz,3], x,y,z as for ndsm_vector_solve; ngrids = level cap (0: reference rule) - a solve
+ *   whose ioptc[get_iopt_ngrids()] differs from it fails with 9002.
+ *   ndsm_hip_vecpot_solve        A, B HOST arrays: contents, options, return value as ndsm_vector_solve.
+ *   ndsm_hip_vecpot_solve_device A, B DEVICE arrays (nx,ny,nz,3) on the library's GPU: B.n is extracted by a
+ *                                kernel, nothing crosses PCIe but six fluxes and the 16-byte convergence
+ *                                read-backs; results are complete in A, B when the call returns. */
+int ndsm_hip_vecpot_create(const int nshape4[4], const double *x, const double *y, const double *z, int ngrids,
+                           void **handle);
+int ndsm_hip_vecpot_solve(void *handle, int ioptc[16], double ropt[16], double *A, double *B);
+int ndsm_hip_vecpot_solve_device(void *handle, int ioptc[16], double ropt[16], double *dA, double *dB);
+int ndsm_hip_vecpot_destroy(void *handle);
+
 /* =====================================================================
  * PART 3 - additive exports, multi-GPU
  *

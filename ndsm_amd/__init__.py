@@ -7,8 +7,8 @@ additive C entry points.  There is no CPU fallback: without the library or
 without an MI355X every call raises.
 """
 from .ndsm import vector_potential, vector_potential_slab, get_lib_path  # noqa: F401
-from ._lib import (load_library, lib_path, MGSolver, World, slab_plan, poisson_solve,  # noqa: F401
+from ._lib import (load_library, lib_path, MGSolver, VecPot, World, slab_plan, poisson_solve,  # noqa: F401
                    NdsmHipError)
 
-__all__ = ["vector_potential", "vector_potential_slab", "get_lib_path", "load_library", "lib_path", "MGSolver", "poisson_solve",
+__all__ = ["vector_potential", "vector_potential_slab", "get_lib_path", "load_library", "lib_path", "MGSolver", "VecPot", "poisson_solve",
            "NdsmHipError"]

@@ -209,6 +209,86 @@ class MGSolver:
         return ms.value
 
 
+class VecPot:
+    """Persistent vector-potential solver (additive): the grid hierarchies, transfer tables
+    and device arrays are built once per (shape, mesh) and reused by every solve().
+
+    x, y, z: mesh vectors; shape of the fields: numpy (3, nz, ny, nx)."""
+
+    def __init__(self, x, y, z, ngrids=0, lib=None):
+        self.L = lib or load_library()
+        self.x, self.y, self.z = _f64(x), _f64(y), _f64(z)
+        self.nshape4 = np.array([len(self.x), len(self.y), len(self.z), 3], dtype=np.intc)
+        self.ngrids = int(ngrids)
+        self.h = ctypes.c_void_p()
+        self.L.ndsm_hip_vecpot_create.argtypes = [_ip, _dp, _dp, _dp, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        self.L.ndsm_hip_vecpot_solve.argtypes = [ctypes.c_void_p, _ip, _dp, _dp, _dp]
+        self.L.ndsm_hip_vecpot_solve_device.argtypes = [ctypes.c_void_p, _ip, _dp, ctypes.c_void_p, ctypes.c_void_p]
+        self.L.ndsm_hip_vecpot_destroy.argtypes = [ctypes.c_void_p]
+        self.L.ndsm_hip_device_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        self.L.ndsm_hip_device_free.argtypes = [ctypes.c_void_p]
+        self.L.ndsm_hip_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        self.L.ndsm_hip_memcpy_d2h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        rc = self.L.ndsm_hip_vecpot_create(self.nshape4.ctypes.data_as(_ip), _d(self.x), _d(self.y), _d(self.z),
+                                           self.ngrids, ctypes.byref(self.h))
+        _check(rc, "ndsm_hip_vecpot_create", self.L)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.ndsm_hip_vecpot_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _options(self, niterex_max, ncycles_max, ex_tol, vc_tol, ms, mean, mixed_precision, flxcrl):
+        L = self.L
+        ioptc = np.zeros(16, dtype=np.intc)
+        ropt = np.zeros(16)
+        ioptc[L.get_iopt_ms()] = ms
+        ioptc[L.get_iopt_ncycles()] = ncycles_max
+        ioptc[L.get_iopt_iopt_nmaxex()] = niterex_max
+        ioptc[L.get_iopt_dumax()] = 0 if mean else 1
+        ioptc[L.get_iopt_ngrids()] = self.ngrids
+        ioptc[L.get_iopt_prec()] = int(mixed_precision)
+        ioptc[4] = 1 if flxcrl else 0          # IOPT_FLXCRL (ndsm_vector_potential.f90:44; no getter in the reference)
+        ropt[L.get_ropt_vtol()] = vc_tol
+        ropt[L.get_ropt_ctol()] = ex_tol
+        return ioptc, ropt
+
+    def solve(self, b, a_init=None, niterex_max=10000, ncycles_max=1024, ex_tol=1e-13, vc_tol=1e-10, ms=5, mean=False,
+              mixed_precision=False, flxcrl=False, device=False):
+        """b: (3,nz,ny,nx); returns (ierr, A, B) like ndsm.vector_potential.  device=True: the fields are
+        staged in device memory first and the device-resident entry point runs (tests of that path)."""
+        ioptc, ropt = self._options(niterex_max, ncycles_max, ex_tol, vc_tol, ms, mean, mixed_precision, flxcrl)
+        shape = tuple(int(v) for v in self.nshape4[::-1])
+        B = _f64(b).reshape(-1).copy()
+        assert B.size == int(np.prod(shape)), (b.shape, shape)
+        A = np.zeros(B.size) if a_init is None else _f64(a_init).reshape(-1).copy()
+        if not device:
+            ierr = self.L.ndsm_hip_vecpot_solve(self.h, ioptc.ctypes.data_as(_ip), _d(ropt), _d(A), _d(B))
+        else:
+            dA, dB = ctypes.c_void_p(), ctypes.c_void_p()
+            _check(self.L.ndsm_hip_device_alloc(A.nbytes, ctypes.byref(dA)), "device_alloc", self.L)
+            _check(self.L.ndsm_hip_device_alloc(B.nbytes, ctypes.byref(dB)), "device_alloc", self.L)
+            try:
+                _check(self.L.ndsm_hip_memcpy_h2d(dA, A.ctypes.data, A.nbytes), "h2d", self.L)
+                _check(self.L.ndsm_hip_memcpy_h2d(dB, B.ctypes.data, B.nbytes), "h2d", self.L)
+                ierr = self.L.ndsm_hip_vecpot_solve_device(self.h, ioptc.ctypes.data_as(_ip), _d(ropt), dA, dB)
+                _check(self.L.ndsm_hip_memcpy_d2h(A.ctypes.data, dA, A.nbytes), "d2h", self.L)
+                _check(self.L.ndsm_hip_memcpy_d2h(B.ctypes.data, dB, B.nbytes), "d2h", self.L)
+            finally:
+                self.L.ndsm_hip_device_free(dA)
+                self.L.ndsm_hip_device_free(dB)
+        if ierr >= 9000:
+            _check(ierr, "ndsm_hip_vecpot_solve", self.L)
+        self.last_ioptc, self.last_ropt = ioptc, ropt
+        return ierr, A.reshape(shape), B.reshape(shape)
+
+
 SLAB_FIELDS = ("rank", "z0", "z1", "g", "nloc", "k0", "ck0", "ck1", "pk0", "pk1", "cb0", "cb1")
 
 

@@ -90,6 +90,20 @@ int ndsmk_sync(void);                                        /* blocking */
 int ndsmk_timer_start(void);                /* hipEventRecord on the library stream */
 int ndsmk_timer_stop(double *ms);           /* blocking; elapsed between start and now */
 
+/* background transfers: one worker thread + copy stream move the caller's host arrays while the main
+ * thread drives the solves.  upload_unless_zero: scan the host array; copy it to d_dst unless every byte
+ * is zero (*flag of ndsmk_bg_wait = 1: nothing copied, the caller zero-fills).  download: starts once the
+ * main stream has passed the point of the call.  Tickets die in ndsmk_bg_drain (blocking, first error). */
+int ndsmk_bg_upload_unless_zero(const void *h_src, void *d_dst, size_t bytes, int *ticket);
+int ndsmk_bg_download(void *h_dst, const void *d_src, size_t bytes, int *ticket);
+int ndsmk_bg_wait(int ticket, int *flag);
+int ndsmk_bg_drain(void);
+int ndsmk_host_alloc(void **p, size_t bytes);               /* pinned */
+int ndsmk_host_free(void *p);
+int ndsmk_mem_info(size_t *free_bytes, size_t *total_bytes);
+int ndsmk_h2d_async(void *dst, const void *h_pinned_src, size_t bytes);
+void ndsmk_at_reset(void (*fn)(void));                      /* fn runs at the next shutdown / re-target */
+
 /* ---- kernels ------------------------------------------------------- */
 /* nsweeps full red-black Gauss-Seidel sweeps (ndsm_optimized.f90:40-191 in
  * 3-D, ndsm_poisson.f90:451-549 in 2-D incl. the all-Neumann mean shift).
@@ -141,6 +155,21 @@ int ndsmk_balance_curl(double *A, double *B, const int32_t *n3, const double *x,
 int ndsmk_balance_curl_slab(double *A, double *B, const int32_t *n3, int kg0, int na, int nb, int boff,
                             const double *x, const double *y, const double *z, const double *h_phi6,
                             const double *h_span3, const double *h_dq3, int curl_first);
+
+/* one component (c = 0,1,2) of the flux-balance fields added to that component of A alone (same
+ * expressions as ndsmk_balance_curl's first kernel: components can be finished one at a time), and the
+ * curl alone: B = curl A on device arrays (nx,ny,nz,3) */
+int ndsmk_balance_component(double *Ac, const int32_t *n3, int c, const double *x, const double *y, const double *z,
+                            const double *h_phi6, const double *h_span3);
+int ndsmk_curl(const double *A, double *B, const int32_t *n3, const double *h_dq3);
+
+/* the face phase on the device (faces.hip): packed face buffers, six faces back to back */
+int ndsmk_face_offsets(const int32_t *n3, int64_t *off6, int64_t *total);
+int ndsmk_face_extract(const double *B, const int32_t *n3, double *faces);
+int ndsmk_face_flux(const double *faces, const int32_t *n3, double h1h2, double *d_phi6);
+int ndsmk_face_rhs(const double *faces, const int32_t *n3, int f, const double *d_phi6, double area, double *rhs);
+int ndsmk_face_write(double *u, const int32_t *n3, const double *chi, int f, int c, double fac);
+int ndsmk_face_put(double *u, const int32_t *n3, int f, const double *vals);
 
 /* level-1 form for the V-cycle driver: three buffers (u on entry + two spares), `keep` (one of them
  * or NULL) is never written, *where = 0/1/2 names the buffer holding the result.  r: residual of the

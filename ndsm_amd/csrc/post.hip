@@ -60,6 +60,34 @@ __global__ __launch_bounds__(256) void balance_k(double *__restrict__ A, double 
   A[c + 2 * N] = A[c + 2 * N] + cz + third * (l1z + l2z + l3z);
 }
 
+// Component C of the same update of A alone (whole field, single domain): the driver finishes and
+// downloads one component while the next one is being solved.  Expressions and order as above.
+template <int C>
+__global__ __launch_bounds__(256) void balance_comp_k(double *__restrict__ Ac, PostArgs p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= p.n[0] || j >= p.n[1]) return;
+  const size_t c = (size_t)i + (size_t)p.n[0] * ((size_t)j + (size_t)p.n[1] * (size_t)k);
+  const double vol = p.span[0] * p.span[1] * p.span[2];
+  const double g1 = (p.phi[1] - p.phi[0]) / vol, g2 = (p.phi[3] - p.phi[2]) / vol, g3 = (p.phi[5] - p.phi[4]) / vol;
+  const double x = p.x[i], y = p.y[j], z = p.z[k];
+  const double third = 1.0 / 3.0;
+  if (C == 0) {
+    const double l1x = -g3 * y * z, l2x = +g2 * z * y, l3x = 0.0;
+    const double cx = -(p.phi[4] * p.span[2] * y / vol);
+    Ac[c] = Ac[c] + cx + third * (l1x + l2x + l3x);
+  } else if (C == 1) {
+    const double l1y = 0.0, l2y = -g1 * x * z, l3y = +g3 * x * z;
+    const double cy = -(p.phi[0] * p.span[0] * z / vol);
+    Ac[c] = Ac[c] + cy + third * (l1y + l2y + l3y);
+  } else {
+    const double l1z = +g1 * x * y, l2z = 0.0, l3z = -g2 * x * y;
+    const double cz = -(p.phi[2] * p.span[1] * x / vol);
+    Ac[c] = Ac[c] + cz + third * (l1z + l2z + l3z);
+  }
+}
+
 // d/dq along one axis at index q of n (stride s), derivq :852-870
 __device__ __forceinline__ double ddq(const double *__restrict__ v, size_t c, int q, int n, size_t s, double h) {
   const double half = 0.5;
@@ -148,6 +176,59 @@ extern "C" int ndsmk_balance_curl_slab(double *A, double *B, const int32_t *n3, 
     hipLaunchKernelGGL(curl_k, gridb, block, 0, s, A, B, p);
     NDSM_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// Ac: DEVICE component c (0,1,2) of A, (nx,ny,nz); x,y,z DEVICE mesh vectors
+extern "C" int ndsmk_balance_component(double *Ac, const int32_t *n3, int c, const double *x, const double *y,
+                                       const double *z, const double *h_phi6, const double *h_span3) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(Ac && c >= 0 && c < 3);
+  PostArgs p;
+  p.kg0 = 0;
+  p.na = p.nb = n3[2];
+  p.boff = 0;
+  for (int d = 0; d < 3; ++d) {
+    p.n[d] = n3[d];
+    p.span[d] = h_span3[d];
+    p.dq[d] = 0.0;
+  }
+  for (int f = 0; f < 6; ++f) p.phi[f] = h_phi6[f];
+  p.x = x;
+  p.y = y;
+  p.z = z;
+  dim3 block(64, 4, 1);
+  dim3 grid((n3[0] + 63) / 64, (n3[1] + 3) / 4, n3[2]);
+  hipStream_t s = ndsm::stream();
+  if (c == 0)
+    hipLaunchKernelGGL(balance_comp_k<0>, grid, block, 0, s, Ac, p);
+  else if (c == 1)
+    hipLaunchKernelGGL(balance_comp_k<1>, grid, block, 0, s, Ac, p);
+  else
+    hipLaunchKernelGGL(balance_comp_k<2>, grid, block, 0, s, Ac, p);
+  NDSM_LAUNCH_CHECK();
+  return 0;
+}
+
+// B = curl A alone, whole field
+extern "C" int ndsmk_curl(const double *A, double *B, const int32_t *n3, const double *h_dq3) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(A && B && n3[0] >= 3 && n3[1] >= 3 && n3[2] >= 3);
+  PostArgs p;
+  p.kg0 = 0;
+  p.na = p.nb = n3[2];
+  p.boff = 0;
+  for (int d = 0; d < 3; ++d) {
+    p.n[d] = n3[d];
+    p.span[d] = 0.0;
+    p.dq[d] = h_dq3[d];
+  }
+  for (int f = 0; f < 6; ++f) p.phi[f] = 0.0;
+  p.x = p.y = p.z = nullptr;
+  dim3 block(64, 4, 1);
+  dim3 grid((n3[0] + 63) / 64, (n3[1] + 3) / 4, n3[2]);
+  hipLaunchKernelGGL(curl_k, grid, block, 0, ndsm::stream(), A, B, p);
+  NDSM_LAUNCH_CHECK();
   return 0;
 }
 

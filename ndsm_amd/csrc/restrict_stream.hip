@@ -16,6 +16,7 @@
 // six to three.
 #include "common.hpp"
 
+#include <cstdlib>
 
 namespace {
 
@@ -260,6 +261,230 @@ __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const TF *__restrict
 #undef RS_STORE
 }
 
+// Second form of the same kernel (default; NDSM_RS_VARIANT=0 selects the one above).  What the first
+// one loses: a workgroup walks ~130 fine planes with ONE plane of prefetch, so every plane-step waits for
+// most of an HBM round trip (counters: 31 % issue utilisation at 3.5 us per plane-step), and its tap
+// loops are predicated per lane (ii < ni).  Here
+//   * three planes are in flight: plane k+3 is requested while plane k is consumed, each in a register
+//     slot of its own (the plane loop is unrolled by three so that the slots are static - a register
+//     that is the target of a load in flight cannot be moved without waiting for it);
+//   * the x tap count is made wave-uniform (the wave's maximum) and the weights of the taps a column does
+//     not have are exact zeros: w * f = +-0 and x + (+-0) = x bit for bit (the running sum starts at +0
+//     and can never become -0), so the padded taps change nothing and the loops need no exec masking.
+//     LDS is zero-filled once so that a padded tap never meets an uninitialised word.
+// Same tap order and weight chain: bit-identical (tests/test_gpu_parity.py::test_transfer3d_bitwise,
+// test_large_level_kernels_bitwise, the V-cycle tests).
+template <typename TF, int CI, int CJ, int MT, int KCMAX, int WPS, bool ODDX>
+__global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__restrict__ f, double *__restrict__ rhs_c,
+                                                                  double *__restrict__ u_c, RSArgs a) {
+  constexpr int NT = CI * CJ;
+  constexpr int FX = 2 * CI + 6, FY = 2 * CJ + 5;
+  constexpr int NPX = FX / 2, NPAIR = NPX * FY, NS = (NPAIR + NT - 1) / NT;
+  constexpr int PLANE = FX * FY;
+  constexpr int LDSN = 2 * PLANE + FX;  // two planes + a pad row for the padded taps of the last rows
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int nb8 = gridDim.x >> 3;
+  const int wk = (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3);
+  if (wk >= a.nwork) return;
+  const int tj = wk % a.ntj;
+  const int t2 = wk / a.ntj;
+  const int ti = t2 % a.nti;
+  const int ck = t2 / a.nti;
+
+  const int nx = a.nf[0], ny = a.nf[1];
+  const size_t sz = (size_t)nx * (size_t)ny;
+  const int I0 = ti * CI, J0 = tj * CJ;
+  const int Ks = a.c_k0 + a.c_beg + ck * a.kc;
+  const int Ke = min(Ks + a.kc, a.c_k0 + a.c_beg + a.c_cnt);
+  const int fx0 = a.rlo[0][I0] & ~1;
+  const int fy0 = a.rlo[1][J0];
+  const int kA = a.rlo[2][Ks];
+  const int kB = a.rlo[2][Ke - 1] + a.rcnt[2][Ke - 1] - 1;
+  const int tid = (int)threadIdx.x;
+
+  for (int t = tid; t < LDSN; t += NT) lds[t] = 0.0;
+
+  const int I = I0 + tid % CI, J = J0 + tid / CI;
+  const bool chave = I < a.nc[0] && J < a.nc[1];
+  int ni = 0, nj = 0, li0 = 0, lj0 = 0;
+  double cxw[MT], cy[MT];
+#pragma unroll
+  for (int q = 0; q < MT; ++q) cxw[q] = cy[q] = 0.0;
+  if (chave) {
+    ni = a.rcnt[0][I];
+    nj = a.rcnt[1][J];
+    li0 = a.rlo[0][I] - fx0;
+    lj0 = a.rlo[1][J] - fy0;
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      // cxw = c2x w2x: first factor of the weight chain ((((c2x w2x) c2y) w2y) c2z) w2z (ndsm_interp.f90:277-282)
+      cxw[q] = q < ni ? a.rw[0][(size_t)I * a.maxt[0] + q] * a.w2[0] : 0.0;
+      cy[q] = q < nj ? a.rw[1][(size_t)J * a.maxt[1] + q] : 0.0;
+    }
+  }
+  __shared__ int s_z0[KCMAX], s_nk[KCMAX];
+  __shared__ double s_zw[KCMAX * MT];
+  for (int t = tid; t < Ke - Ks; t += NT) {
+    const int nk = a.rcnt[2][Ks + t];
+    s_z0[t] = a.rlo[2][Ks + t];
+    s_nk[t] = nk;
+    for (int q = 0; q < MT; ++q) s_zw[t * MT + q] = q < nk ? a.rw[2][(size_t)(Ks + t) * a.maxt[2] + q] : 0.0;
+  }
+  // wave-uniform tap counts: a wave is one row of coarse columns (one J); x: the wave's maximum
+  const int njw = __builtin_amdgcn_readfirstlane(nj);
+  int nim = ni;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nim = max(nim, __shfl_xor(nim, o, 64));
+  nim = __builtin_amdgcn_readfirstlane(nim);
+
+  // staging geometry of this thread's NS pairs.  Loads are UNCONDITIONAL - from a clamped, always valid
+  // address - and what must not enter the tile is replaced by zero when the slot is written to LDS: a load
+  // under a branch is waited for at the join right behind it (the compiler cannot keep a value that exists
+  // on one path only in flight), which turns every prefetch into a synchronous load.
+  int goff[NS], loff[NS];
+  bool gx0[NS], gx1[NS];   // element 0 / 1 of the pair lies inside the fine grid
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_) {
+    const int p_ = tid + NT * s_;
+    const int lj_ = p_ / NPX, li_ = 2 * (p_ - lj_ * NPX);
+    const int i_ = fx0 + li_, j_ = fy0 + lj_;
+    loff[s_] = p_ < NPAIR ? li_ + FX * lj_ : -1;
+    const bool in = p_ < NPAIR && i_ < nx && j_ < ny;
+    gx0[s_] = in;
+    gx1[s_] = in && i_ + 1 < nx;
+    goff[s_] = in ? i_ + nx * j_ : 0;
+  }
+  auto load_plane = [&](int kglob, d2(&dst)[NS]) {
+    const TF *pk = f + sz * (size_t)(min(kglob, kB) - a.f_k0);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const TF *q_ = pk + goff[s_];
+      if (!ODDX) {
+        dst[s_] = ld2(q_);
+      } else {       // odd nx: rows are not 16-byte aligned (element loads) and the last pair is half outside
+        dst[s_].x = (double)q_[0];
+        dst[s_].y = (double)q_[gx1[s_] ? 1 : 0];
+      }
+    }
+  };
+  auto store_plane = [&](double *buf, const d2(&src)[NS], bool plane_ok) {
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      d2 v = src[s_];
+      v.x = (plane_ok && gx0[s_]) ? v.x : 0.0;
+      v.y = (plane_ok && gx1[s_]) ? v.y : 0.0;
+      if (loff[s_] >= 0) st2(buf + loff[s_], v);
+    }
+  };
+
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;  // coarse planes K with K & 3 = 0..3
+  int Klo = Ks;
+  auto getacc = [&](int slot) { return slot == 0 ? acc0 : (slot == 1 ? acc1 : (slot == 2 ? acc2 : acc3)); };
+  auto finish = [&](int K, double fc, bool complete) {
+    if (complete) {
+      if (chave) {
+        const size_t c = (size_t)I + (size_t)a.nc[0] * ((size_t)J + (size_t)a.nc[1] * (size_t)(K - a.c_k0));
+        rhs_c[c] = fc;
+        if (u_c) u_c[c] = 0.0;  // ndsm_multigrid_core.f90:557-558
+      }
+      fc = 0.0;
+    }
+    const int slot = K & 3;
+    acc0 = slot == 0 ? fc : acc0;
+    acc1 = slot == 1 ? fc : acc1;
+    acc2 = slot == 2 ? fc : acc2;
+    acc3 = slot == 3 ? fc : acc3;
+  };
+
+  // the taps of fine plane k (in LDS buffer R) for every coarse plane whose z window holds it
+  auto consume = [&](int k, const double *R) {
+    const double *P = R + li0 + FX * lj0;
+    int K = Klo;
+    while (K < Ke) {
+      const int z0 = __builtin_amdgcn_readfirstlane(s_z0[K - Ks]);
+      if (z0 > k) break;
+      const int nk = __builtin_amdgcn_readfirstlane(s_nk[K - Ks]);
+      if (k >= z0 + nk) {
+        ++K;
+        continue;
+      }
+      int z1 = 0, nk1 = 0;
+      bool two = false;
+      if (K + 1 < Ke) {
+        z1 = __builtin_amdgcn_readfirstlane(s_z0[K + 1 - Ks]);
+        nk1 = __builtin_amdgcn_readfirstlane(s_nk[K + 1 - Ks]);
+        two = z1 <= k && k < z1 + nk1;
+      }
+      const double c2za = s_zw[(K - Ks) * MT + (k - z0)];
+      double fa = getacc(K & 3);
+      if (two) {
+        const double c2zb = s_zw[(K + 1 - Ks) * MT + (k - z1)];
+        double fb = getacc((K + 1) & 3);
+#pragma unroll
+        for (int jj = 0; jj < MT; ++jj) {
+          if (jj < njw) {
+#pragma unroll
+            for (int ii = 0; ii < MT; ++ii) {
+              if (ii < nim) {
+                const double w0 = cxw[ii] * cy[jj] * a.w2[1];
+                const double wa = w0 * c2za * a.w2[2];
+                const double wb = w0 * c2zb * a.w2[2];
+                const double fv = P[ii + FX * jj];
+                fa = fa + wa * fv;
+                fb = fb + wb * fv;
+              }
+            }
+          }
+        }
+        finish(K, fa, k == z0 + nk - 1);
+        finish(K + 1, fb, k == z1 + nk1 - 1);
+        K += 2;
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < MT; ++jj) {
+          if (jj < njw) {
+#pragma unroll
+            for (int ii = 0; ii < MT; ++ii) {
+              if (ii < nim) {
+                const double w0 = cxw[ii] * cy[jj] * a.w2[1];
+                const double wa = w0 * c2za * a.w2[2];
+                fa = fa + wa * P[ii + FX * jj];
+              }
+            }
+          }
+        }
+        finish(K, fa, k == z0 + nk - 1);
+        K += 1;
+      }
+    }
+    while (Klo < Ke && __builtin_amdgcn_readfirstlane(s_z0[Klo - Ks] + s_nk[Klo - Ks]) - 1 <= k) ++Klo;
+  };
+
+  // ---- prologue: plane kA into LDS buffer 0, planes kA+1, kA+2 on their way ----
+  d2 r0[NS], r1[NS], r2[NS];
+  __syncthreads();  // the zero fill is complete
+  load_plane(kA, r0);
+  load_plane(kA + 1, r1);
+  load_plane(kA + 2, r2);
+  store_plane(lds, r0, true);
+  __syncthreads();  // also publishes the z tables
+
+  // one plane-step: request plane k+3 into the slot plane k came from, consume plane k, move plane k+1
+  // from its slot into the other LDS buffer
+  auto step = [&](int k, d2(&slot_k)[NS], const d2(&slot_k1)[NS]) {
+    load_plane(k + 3, slot_k);
+    consume(k, lds + ((k - kA) & 1) * PLANE);
+    store_plane(lds + ((k + 1 - kA) & 1) * PLANE, slot_k1, k + 1 <= kB);
+    __syncthreads();
+  };
+  for (int k = kA; k <= kB; k += 3) {
+    step(k, r0, r1);
+    if (k + 1 <= kB) step(k + 1, r1, r2);
+    if (k + 2 <= kB) step(k + 2, r2, r0);
+  }
+}
+
 constexpr int kCI = 64, kCJ = 8, kMT = 5, kKCMax = 64;
 
 }  // namespace
@@ -324,13 +549,29 @@ static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
   a.nkc = (x->c_cnt + kc - 1) / kc;
   a.nwork = tiles * a.nkc;
   const int nblk = ((a.nwork + 7) / 8) * 8;
-  constexpr size_t lds_bytes = sizeof(double) * 2 * (2 * kCI + 6) * (2 * kCJ + 5);
-  auto kfn = restrict_stream_k<TF, kCI, kCJ, kMT, kKCMax>;
-  static int attr_epoch = 0;
-  if (ndsm::first_in_epoch(attr_epoch))
-    NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds_bytes));
-  hipLaunchKernelGGL(kfn, dim3(nblk), dim3(kCI * kCJ), lds_bytes, stream(), r_f, rhs_c, u_c, a);
+  static int variant = -1;
+  if (variant < 0) {
+    const char *e = std::getenv("NDSM_RS_VARIANT");
+    variant = e ? std::atoi(e) : 1;
+  }
+  if (variant == 0) {
+    constexpr size_t lds_bytes = sizeof(double) * 2 * (2 * kCI + 6) * (2 * kCJ + 5);
+    auto kfn = restrict_stream_k<TF, kCI, kCJ, kMT, kKCMax>;
+    static int attr_epoch = 0;
+    if (ndsm::first_in_epoch(attr_epoch))
+      NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes));
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(kCI * kCJ), lds_bytes, stream(), r_f, rhs_c, u_c, a);
+  } else {
+    constexpr size_t lds_bytes = sizeof(double) * (2 * (2 * kCI + 6) * (2 * kCJ + 5) + (2 * kCI + 6));
+    auto kfn = (x->nf[0] & 1) ? restrict_stream2_k<TF, kCI, kCJ, kMT, kKCMax, 4, true>
+                              : restrict_stream2_k<TF, kCI, kCJ, kMT, kKCMax, 4, false>;
+    static int attr_epoch[2] = {0, 0};
+    if (ndsm::first_in_epoch(attr_epoch[x->nf[0] & 1]))
+      NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes));
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(kCI * kCJ), lds_bytes, stream(), r_f, rhs_c, u_c, a);
+  }
   NDSM_LAUNCH_CHECK();
   return 0;
 }

@@ -6,7 +6,11 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -24,12 +28,120 @@ struct Runtime {
 
 Runtime g_rt;
 std::mutex g_mu;
+// ---- background transfers (ndsmk_bg_*): one worker thread with a copy stream of its own moves the
+// caller's host arrays while the main thread drives the solves (DESIGN.md "end to end") ----
+struct BgJob {
+  int kind = 0;                 // 0 upload-unless-zero, 1 download
+  void *h = nullptr;
+  void *d = nullptr;
+  size_t bytes = 0;
+  hipEvent_t after = nullptr;   // download: main-stream work that must be complete first
+  int rc = 0;
+  int flag = 0;                 // upload: 1 = the host array was all zero (nothing was copied)
+  bool done = false;
+};
+struct BgState {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::deque<std::shared_ptr<BgJob>> queue;
+  std::vector<std::shared_ptr<BgJob>> tickets;
+  bool quit = false, running = false;
+  hipStream_t copy = nullptr;
+  int device = 0;
+};
+// on the heap and never destroyed: at process exit the worker may still sit in cv_work.wait, and
+// destroying a condition variable (or a joinable std::thread) under it hangs or aborts the process
+BgState &g_bg = *new BgState;
+
+// all-zero test of a host array, up to four threads (3 GiB of initial guess: ~0.1 s on one core)
+bool host_all_zero(const void *p, size_t bytes) {
+  const size_t nw = bytes / 8;
+  const uint64_t *w = static_cast<const uint64_t *>(p);
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt > 4 ? 4 : (nt < 1 ? 1 : nt);
+  if (nw < (size_t)1 << 22) nt = 1;
+  std::vector<int> nz(nt, 0);
+  auto scan = [&](unsigned t) {
+    const size_t a = nw * t / nt, b = nw * (t + 1) / nt;
+    uint64_t acc = 0;
+    size_t i = a;
+    for (; i + 8 <= b; i += 8) {
+      acc |= w[i] | w[i + 1] | w[i + 2] | w[i + 3] | w[i + 4] | w[i + 5] | w[i + 6] | w[i + 7];
+      if (acc) break;                       // leave early once something was seen
+    }
+    for (; i < b && !acc; ++i) acc |= w[i];
+    nz[t] = acc != 0;
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(scan, t);
+  scan(0);
+  for (auto &x : th) x.join();
+  for (unsigned t = 0; t < nt; ++t)
+    if (nz[t]) return false;
+  const unsigned char *tail = static_cast<const unsigned char *>(p) + nw * 8;
+  for (size_t i = 0; i < bytes - nw * 8; ++i)
+    if (tail[i]) return false;
+  return true;   // note: -0.0 has a non-zero bit pattern and counts as data
+}
+
+void bg_worker() {
+  (void)hipSetDevice(g_bg.device);
+  for (;;) {
+    std::shared_ptr<BgJob> j;
+    {
+      std::unique_lock<std::mutex> lk(g_bg.mu);
+      g_bg.cv_work.wait(lk, [] { return g_bg.quit || !g_bg.queue.empty(); });
+      if (g_bg.queue.empty()) return;
+      j = g_bg.queue.front();
+      g_bg.queue.pop_front();
+    }
+    hipError_t e = hipSuccess;
+    if (j->kind == 0) {
+      j->flag = host_all_zero(j->h, j->bytes) ? 1 : 0;
+      if (!j->flag) {
+        e = hipMemcpyAsync(j->d, j->h, j->bytes, hipMemcpyHostToDevice, g_bg.copy);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_bg.copy);
+      }
+    } else {
+      e = hipStreamWaitEvent(g_bg.copy, j->after, 0);
+      if (e == hipSuccess) e = hipMemcpyAsync(j->h, j->d, j->bytes, hipMemcpyDeviceToHost, g_bg.copy);
+      if (e == hipSuccess) e = hipStreamSynchronize(g_bg.copy);
+    }
+    {
+      std::lock_guard<std::mutex> lk(g_bg.mu);
+      j->rc = (int)e;
+      j->done = true;
+    }
+    g_bg.cv_done.notify_all();
+  }
+}
+
+void bg_stop() {
+  if (!g_bg.running) return;
+  {
+    std::lock_guard<std::mutex> lk(g_bg.mu);
+    g_bg.quit = true;
+  }
+  g_bg.cv_work.notify_all();
+  g_bg.th.join();
+  for (auto &j : g_bg.tickets)
+    if (j->after) (void)hipEventDestroy(j->after);
+  g_bg.tickets.clear();
+  g_bg.queue.clear();
+  if (g_bg.copy) (void)hipStreamDestroy(g_bg.copy);
+  g_bg.copy = nullptr;
+  g_bg.quit = false;
+  g_bg.running = false;
+}
+
 int g_epoch = 0;                       // see common.hpp
 std::vector<void (*)()> g_reset_hooks;
 
 // the runtime is going away (shutdown or re-target): drain, let every translation unit drop what it
 // holds on this device, then destroy streams and events
 void tear_down() {
+  bg_stop();
   (void)hipStreamSynchronize(g_rt.stream);
   (void)hipStreamSynchronize(g_rt.comm);
   std::vector<void (*)()> hooks;
@@ -200,6 +312,114 @@ int ndsmk_stream_fence(int from, int to) {
   NDSM_HIP(hipStreamWaitEvent(to ? g_rt.comm : g_rt.stream, g_rt.evx, 0));
   return 0;
 }
+
+// ---- background transfers ------------------------------------------------------------------
+static int bg_submit(std::shared_ptr<BgJob> j, int *ticket) {
+  if (!g_bg.running) {
+    g_bg.device = g_rt.device;
+    NDSM_HIP(hipStreamCreateWithFlags(&g_bg.copy, hipStreamNonBlocking));
+    g_bg.quit = false;
+    g_bg.th = std::thread(bg_worker);
+    g_bg.running = true;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_bg.mu);
+    g_bg.tickets.push_back(j);
+    *ticket = (int)g_bg.tickets.size() - 1;
+    g_bg.queue.push_back(j);
+  }
+  g_bg.cv_work.notify_one();
+  return 0;
+}
+
+// queue: if the host array is not all zero, copy it to d_dst (the caller zero-fills d_dst itself when
+// ndsmk_bg_wait reports flag = 1).  Returns at once; *ticket names the job.
+int ndsmk_bg_upload_unless_zero(const void *h_src, void *d_dst, size_t bytes, int *ticket) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(h_src && d_dst && ticket);
+  auto j = std::make_shared<BgJob>();
+  j->kind = 0;
+  j->h = const_cast<void *>(h_src);
+  j->d = d_dst;
+  j->bytes = bytes;
+  return bg_submit(j, ticket);
+}
+
+// queue: once everything enqueued on the main stream SO FAR has finished, copy d_src to the host array
+int ndsmk_bg_download(void *h_dst, const void *d_src, size_t bytes, int *ticket) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(h_dst && d_src && ticket);
+  auto j = std::make_shared<BgJob>();
+  j->kind = 1;
+  j->h = h_dst;
+  j->d = const_cast<void *>(d_src);
+  j->bytes = bytes;
+  NDSM_HIP(hipEventCreateWithFlags(&j->after, hipEventDisableTiming));
+  NDSM_HIP(hipEventRecord(j->after, g_rt.stream));
+  return bg_submit(j, ticket);
+}
+
+// blocking: job `ticket` has finished; *flag (may be NULL) = its all-zero verdict (uploads)
+int ndsmk_bg_wait(int ticket, int *flag) {
+  NDSM_REQUIRE_READY();
+  std::shared_ptr<BgJob> j;
+  {
+    std::unique_lock<std::mutex> lk(g_bg.mu);
+    NDSM_CHECK_ARG(ticket >= 0 && ticket < (int)g_bg.tickets.size());
+    j = g_bg.tickets[ticket];
+    g_bg.cv_done.wait(lk, [&] { return j->done; });
+  }
+  if (flag) *flag = j->flag;
+  if (j->rc) return ndsm::fail(j->rc, hipGetErrorString((hipError_t)j->rc), __FILE__, __LINE__);
+  return 0;
+}
+
+// blocking: every queued job has finished; tickets are void afterwards.  Returns the first error.
+int ndsmk_bg_drain(void) {
+  if (!g_bg.running) return 0;
+  int rc = 0;
+  std::vector<std::shared_ptr<BgJob>> all;
+  {
+    std::unique_lock<std::mutex> lk(g_bg.mu);
+    g_bg.cv_done.wait(lk, [] {
+      for (auto &j : g_bg.tickets)
+        if (!j->done) return false;
+      return true;
+    });
+    all.swap(g_bg.tickets);
+  }
+  for (auto &j : all) {
+    if (j->after) (void)hipEventDestroy(j->after);
+    if (j->rc && !rc) rc = j->rc;
+  }
+  if (rc) return ndsm::fail(rc, hipGetErrorString((hipError_t)rc), __FILE__, __LINE__);
+  return 0;
+}
+
+// pinned host memory (staging of the six boundary faces), device memory figures
+int ndsmk_host_alloc(void **p, size_t bytes) {
+  NDSM_REQUIRE_READY();
+  *p = nullptr;
+  NDSM_HIP(hipHostMalloc(p, bytes ? bytes : 8, hipHostMallocDefault));
+  return 0;
+}
+int ndsmk_host_free(void *p) {
+  if (!p) return 0;
+  NDSM_HIP(hipHostFree(p));
+  return 0;
+}
+int ndsmk_mem_info(size_t *free_bytes, size_t *total_bytes) {
+  NDSM_REQUIRE_READY();
+  NDSM_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return 0;
+}
+// asynchronous on the main stream (h_src must be pinned and stay untouched until the stream has passed it)
+int ndsmk_h2d_async(void *dst, const void *h_src, size_t bytes) {
+  NDSM_REQUIRE_READY();
+  NDSM_HIP(hipMemcpyAsync(dst, h_src, bytes, hipMemcpyHostToDevice, g_rt.stream));
+  return 0;
+}
+void ndsmk_at_reset(void (*fn)(void)) { ndsm::at_reset(fn); }
 
 int ndsmk_timer_start(void) {
   NDSM_REQUIRE_READY();

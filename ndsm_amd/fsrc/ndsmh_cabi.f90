@@ -581,6 +581,129 @@ contains
     rc = mg_read_info(s, sweeps, unconverged)
   end function
 
+  ! ---- device memory for callers without a HIP binding of their own (ctypes) ----
+  function ndsm_hip_device_alloc(bytes, p) bind(c, name="ndsm_hip_device_alloc") result(rc)
+    integer(c_size_t), value :: bytes
+    type(c_ptr), intent(out) :: p
+    integer(c_int) :: rc
+    p = c_null_ptr
+    rc = ndsmk_init(-1_c_int)
+    if (rc == 0) rc = ndsmk_alloc(p, bytes)
+  end function
+  function ndsm_hip_device_free(p) bind(c, name="ndsm_hip_device_free") result(rc)
+    type(c_ptr), value :: p
+    integer(c_int) :: rc
+    rc = ndsmk_free(p)
+  end function
+  function ndsm_hip_memcpy_h2d(d_dst, h_src, bytes) bind(c, name="ndsm_hip_memcpy_h2d") result(rc)
+    type(c_ptr), value :: d_dst, h_src
+    integer(c_size_t), value :: bytes
+    integer(c_int) :: rc
+    rc = ndsmk_h2d(d_dst, h_src, bytes)
+  end function
+  function ndsm_hip_memcpy_d2h(h_dst, d_src, bytes) bind(c, name="ndsm_hip_memcpy_d2h") result(rc)
+    type(c_ptr), value :: h_dst, d_src
+    integer(c_size_t), value :: bytes
+    integer(c_int) :: rc
+    rc = ndsmk_d2h(h_dst, d_src, bytes)
+  end function
+
+  ! ---- persistent vector-potential handle (SURVEY 8f-4) ------------------
+  ! Everything that depends on the grid alone - the 3-D hierarchy and its transfer tables, the three
+  ! 2-D face hierarchies, device arrays for A, B and the faces - lives in the handle; a solve moves
+  ! boundary data in and results out.  (ndsm_vector_solve keeps one such context internally, keyed by
+  ! shape and mesh.)
+  function ndsm_hip_vecpot_create(nshape4, x, y, z, ngrids, handle) bind(c, name="ndsm_hip_vecpot_create") result(rc)
+    integer(c_int), intent(in) :: nshape4(4)
+    type(c_ptr), value :: x, y, z
+    integer(c_int), value :: ngrids
+    type(c_ptr), intent(out) :: handle
+    integer(c_int) :: rc
+    type(vecpot_ctx), pointer :: ctx
+    real(c_double), pointer :: qx(:), qy(:), qz(:)
+    integer(c_int32_t) :: n3(3)
+    handle = c_null_ptr
+    rc = NDSMK_EARG
+    n3 = nshape4(1:3)
+    if (nshape4(4) /= 3 .or. any(n3 < 3)) return
+    if (.not. (c_associated(x) .and. c_associated(y) .and. c_associated(z))) return
+    call c_f_pointer(x, qx, [n3(1)])
+    call c_f_pointer(y, qy, [n3(2)])
+    call c_f_pointer(z, qz, [n3(3)])
+    allocate (ctx)
+    rc = vecpot_ctx_create(ctx, n3, qx, qy, qz, int(ngrids))
+    if (rc /= 0) then
+      call report("ndsm_hip_vecpot_create", rc)
+      call vecpot_ctx_destroy(ctx)
+      deallocate (ctx)
+      return
+    end if
+    handle = c_loc(ctx)
+  end function
+
+  function ndsm_hip_vecpot_destroy(handle) bind(c, name="ndsm_hip_vecpot_destroy") result(rc)
+    type(c_ptr), value :: handle
+    integer(c_int) :: rc
+    type(vecpot_ctx), pointer :: ctx
+    rc = 0
+    if (.not. c_associated(handle)) return
+    call c_f_pointer(handle, ctx)
+    call vecpot_ctx_destroy(ctx)
+    deallocate (ctx)
+  end function
+
+  ! A, B: HOST arrays (nx,ny,nz,3), contents and options exactly as for ndsm_vector_solve
+  function ndsm_hip_vecpot_solve(handle, ioptc, ropt, A, B) bind(c, name="ndsm_hip_vecpot_solve") result(ierr)
+    type(c_ptr), value :: handle, A, B
+    integer(c_int), intent(inout) :: ioptc(0:OPT_LEN - 1)
+    real(c_double), intent(inout) :: ropt(0:OPT_LEN - 1)
+    integer(c_int) :: ierr
+    ierr = vecpot_handle_solve(handle, ioptc, ropt, A, B, .false., "ndsm_hip_vecpot_solve")
+  end function
+
+  ! A, B: DEVICE arrays (nx,ny,nz,3) of the GPU the library runs on (e.g. torch tensors' data_ptr()):
+  ! nothing but six fluxes and the per-cycle 16-byte convergence read-backs crosses PCIe.  The call
+  ! returns when the results are complete in A and B (the library stream is drained).
+  function ndsm_hip_vecpot_solve_device(handle, ioptc, ropt, dA, dB) bind(c, name="ndsm_hip_vecpot_solve_device") &
+      result(ierr)
+    type(c_ptr), value :: handle, dA, dB
+    integer(c_int), intent(inout) :: ioptc(0:OPT_LEN - 1)
+    real(c_double), intent(inout) :: ropt(0:OPT_LEN - 1)
+    integer(c_int) :: ierr
+    ierr = vecpot_handle_solve(handle, ioptc, ropt, dA, dB, .true., "ndsm_hip_vecpot_solve_device")
+  end function
+
+  function vecpot_handle_solve(handle, ioptc, ropt, A, B, on_device, who) result(ierr)
+    type(c_ptr), intent(in) :: handle, A, B
+    integer(c_int), intent(inout) :: ioptc(0:OPT_LEN - 1)
+    real(c_double), intent(inout) :: ropt(0:OPT_LEN - 1)
+    logical, intent(in) :: on_device
+    character(len=*), intent(in) :: who
+    integer(c_int) :: ierr
+    type(vecpot_ctx), pointer :: ctx
+    integer(ik) :: iopt(0:OPT_LEN - 1)
+    real(c_double) :: t0
+    integer(c_int) :: rc
+    ierr = NDSMK_EARG
+    if (.not. (c_associated(handle) .and. c_associated(A) .and. c_associated(B))) return
+    call c_f_pointer(handle, ctx)
+    if (.not. ctx%live) return
+    iopt = ioptc
+    verbose = (iopt(IOPT_DEBUG) == 1)
+    t0 = wall_seconds()
+    rc = NDSMK_EARG
+    if (int(iopt(IOPT_NGRIDS)) == ctx%ngr) rc = vecpot_run(ctx, iopt, ropt, A, B, on_device)
+    ropt(ROPT_TIM) = wall_seconds() - t0
+    ioptc = int(iopt, c_int)
+    if (rc /= 0) then
+      call report(who, rc)
+      ioptc(IOPT_IERR) = rc
+      ierr = rc
+    else
+      ierr = int(iopt(IOPT_IERR), c_int)
+    end if
+  end function
+
   ! ---- z-slab decomposition over GPUs (SURVEY 8e) -----------------------
 
   ! rank 0 creates the 128-byte RCCL id; the launcher hands it to every rank

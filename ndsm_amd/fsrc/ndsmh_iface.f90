@@ -299,6 +299,119 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    ! ---- background transfers, pinned memory (runtime.hip) ----
+    function ndsmk_bg_upload_unless_zero(h_src, d_dst, bytes, ticket) bind(c, name="ndsmk_bg_upload_unless_zero") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: h_src, d_dst
+      integer(c_size_t), value :: bytes
+      integer(c_int), intent(out) :: ticket
+      integer(c_int) :: rc
+    end function
+    function ndsmk_bg_download(h_dst, d_src, bytes, ticket) bind(c, name="ndsmk_bg_download") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: h_dst, d_src
+      integer(c_size_t), value :: bytes
+      integer(c_int), intent(out) :: ticket
+      integer(c_int) :: rc
+    end function
+    function ndsmk_bg_wait(ticket, flag) bind(c, name="ndsmk_bg_wait") result(rc)
+      import :: c_int
+      integer(c_int), value :: ticket
+      integer(c_int), intent(out) :: flag
+      integer(c_int) :: rc
+    end function
+    function ndsmk_bg_drain() bind(c, name="ndsmk_bg_drain") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
+    function ndsmk_host_alloc(p, bytes) bind(c, name="ndsmk_host_alloc") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), intent(out) :: p
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: rc
+    end function
+    function ndsmk_host_free(p) bind(c, name="ndsmk_host_free") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p
+      integer(c_int) :: rc
+    end function
+    function ndsmk_mem_info(free_bytes, total_bytes) bind(c, name="ndsmk_mem_info") result(rc)
+      import :: c_size_t, c_int
+      integer(c_size_t), intent(out) :: free_bytes, total_bytes
+      integer(c_int) :: rc
+    end function
+    function ndsmk_h2d_async(dst, src, bytes) bind(c, name="ndsmk_h2d_async") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: dst, src
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: rc
+    end function
+    subroutine ndsmk_at_reset(fn) bind(c, name="ndsmk_at_reset")
+      import :: c_funptr
+      type(c_funptr), value :: fn
+    end subroutine
+
+    ! ---- one component of the flux balance, the curl alone (post.hip) ----
+    function ndsmk_balance_component(Ac, n3, c, x, y, z, phi6, span3) bind(c, name="ndsmk_balance_component") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: Ac, x, y, z
+      integer(c_int32_t), intent(in) :: n3(3)
+      integer(c_int), value :: c
+      real(c_double), intent(in) :: phi6(6), span3(3)
+      integer(c_int) :: rc
+    end function
+    function ndsmk_curl(A, B, n3, dq3) bind(c, name="ndsmk_curl") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: A, B
+      integer(c_int32_t), intent(in) :: n3(3)
+      real(c_double), intent(in) :: dq3(3)
+      integer(c_int) :: rc
+    end function
+
+    ! ---- the face phase on the device (faces.hip) ----
+    function ndsmk_face_offsets(n3, off6, total) bind(c, name="ndsmk_face_offsets") result(rc)
+      import :: c_int, c_int32_t, c_int64_t
+      integer(c_int32_t), intent(in) :: n3(3)
+      integer(c_int64_t), intent(out) :: off6(6), total
+      integer(c_int) :: rc
+    end function
+    function ndsmk_face_extract(B, n3, faces) bind(c, name="ndsmk_face_extract") result(rc)
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: B, faces
+      integer(c_int32_t), intent(in) :: n3(3)
+      integer(c_int) :: rc
+    end function
+    function ndsmk_face_flux(faces, n3, h1h2, d_phi6) bind(c, name="ndsmk_face_flux") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: faces, d_phi6
+      integer(c_int32_t), intent(in) :: n3(3)
+      real(c_double), value :: h1h2
+      integer(c_int) :: rc
+    end function
+    function ndsmk_face_rhs(faces, n3, f, d_phi6, area, rhs) bind(c, name="ndsmk_face_rhs") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: faces, d_phi6, rhs
+      integer(c_int32_t), intent(in) :: n3(3)
+      integer(c_int), value :: f
+      real(c_double), value :: area
+      integer(c_int) :: rc
+    end function
+    function ndsmk_face_put(u, n3, f, vals) bind(c, name="ndsmk_face_put") result(rc)
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: u, vals
+      integer(c_int32_t), intent(in) :: n3(3)
+      integer(c_int), value :: f
+      integer(c_int) :: rc
+    end function
+    function ndsmk_face_write(u, n3, chi, f, c, fac) bind(c, name="ndsmk_face_write") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: u, chi
+      integer(c_int32_t), intent(in) :: n3(3)
+      integer(c_int), value :: f, c
+      real(c_double), value :: fac
+      integer(c_int) :: rc
+    end function
+
   end interface
 
 contains

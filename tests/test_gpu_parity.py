@@ -1177,3 +1177,66 @@ def test_full_size_config4_loopback_poisson(hip):
     S.close()
     assert list(hw) == list(hs) and du_w == du_s
     assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------
+# the face phase on the device, the persistent vector-potential context
+# ---------------------------------------------------------------------------
+def _vp_cases():
+    x, y, z, _A1, b = analytic_case([40, 33, 36])
+    bn = b + 0.3 * np.random.default_rng(5).uniform(-1, 1, b.shape)       # unbalanced fluxes
+    return x, y, z, b, bn
+
+
+@pytest.mark.gpu
+def test_device_face_phase_equals_host_face_phase(hip):
+    """B.n extraction / fluxes / right-hand sides / A_t / face writes as device kernels (faces.hip) against
+    the host face phase (vecpot_faces, the code the distributed driver's rank 0 runs; selected with
+    NDSM_HIP_HOST_FACES): the same bits in A and B - balanced and unbalanced boundary data, non-zero
+    initial guess, both flux-balance orders"""
+    import ndsm_amd
+    x, y, z, b, bn = _vp_cases()
+    a0 = np.random.default_rng(6).uniform(-1, 1, b.shape)
+    V = ndsm_amd.VecPot(x, y, z)
+    for field, guess, flx in ((b, None, False), (bn, None, False), (bn, a0, False), (bn, a0, True)):
+        os.environ["NDSM_HIP_HOST_FACES"] = "1"
+        try:
+            i1, A1, B1 = V.solve(field, a_init=guess, flxcrl=flx)
+        finally:
+            os.environ.pop("NDSM_HIP_HOST_FACES", None)
+        i2, A2, B2 = V.solve(field, a_init=guess, flxcrl=flx)
+        i3, A3, B3 = V.solve(field, a_init=guess, flxcrl=flx, device=True)      # device-resident entry
+        assert i1 == i2 == i3
+        assert np.array_equal(A1, A2) and np.array_equal(B1, B2), (guess is not None, flx)
+        assert np.array_equal(A2, A3) and np.array_equal(B2, B3), (guess is not None, flx)
+    V.close()
+
+
+@pytest.mark.gpu
+def test_vecpot_context_reuse_and_cache(hip, port):
+    """the persistent context: (a) a handle solves different boundary data one after the other and
+    returns what fresh ndsm_vector_solve calls return; (b) ndsm_vector_solve's internal cache - same mesh
+    again, another mesh, the first mesh again, NDSM_HIP_NO_CACHE - never changes a bit; (c) the oracle
+    bound of the pipeline still holds"""
+    import ndsm_amd
+    x, y, z, b, bn = _vp_cases()
+    x2, y2, z2, _A, b2 = analytic_case([24, 40, 28])
+    os.environ["NDSM_HIP_NO_CACHE"] = "1"
+    try:
+        ref = [ndsm_amd.vector_potential(x, y, z, f.copy()) for f in (b, bn)]
+        ref2 = ndsm_amd.vector_potential(x2, y2, z2, b2.copy())
+    finally:
+        os.environ.pop("NDSM_HIP_NO_CACHE", None)
+    V = ndsm_amd.VecPot(x, y, z)
+    for k in (0, 1, 0):
+        ie, A, B = V.solve((b, bn)[k])
+        assert ie == ref[k][0] and np.array_equal(A, ref[k][1]) and np.array_equal(B, ref[k][2]), k
+    V.close()
+    for k, (xx, yy, zz, ff, want) in enumerate(((x, y, z, b, ref[0]), (x, y, z, bn, ref[1]), (x2, y2, z2, b2, ref2),
+                                                (x, y, z, b, ref[0]))):
+        ie, A, B = ndsm_amd.vector_potential(xx, yy, zz, ff.copy())
+        assert ie == want[0] and np.array_equal(A, want[1]) and np.array_equal(B, want[2]), k
+    ierr2, A2, B2, _io, _ro = port.vector_potential(x, y, z, b)
+    assert np.abs(ref[0][1] - A2).max() <= 1e-12 * np.abs(A2).max()
+    h = x[1] - x[0]
+    assert np.abs(ref[0][2] - B2).max() <= 1e-12 * np.abs(A2).max() * 4 / h
