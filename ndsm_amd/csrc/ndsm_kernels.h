@@ -203,6 +203,7 @@ int ndsmk_prolong_add_f32(const ndsmk_xfer *x, const double *u_c, float *e_f);
 
 /* tests / tuning: the five values of NDSM_FUSED_CFG (smooth_fused.hip) at run time */
 int ndsmk_debug_fused_cfg(int two, int one, int res, int work_items, int big);
+int ndsmk_debug_tile_max(long long max_points);   /* smooth_tile.hip: levels of up to that many points use it (0 none) */
 
 #ifdef __cplusplus
 }

@@ -485,7 +485,21 @@ __global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__re
   }
 }
 
-constexpr int kCI = 64, kCJ = 8, kMT = 5, kKCMax = 64;
+constexpr int kCI = 64, kMT = 5, kKCMax = 64;
+
+// which form of the kernel runs (NDSM_RS_VARIANT; tuning aid): 0 the first kernel (64 x 8 coarse columns,
+// one plane of prefetch), 1 restrict_stream2_k with 64 x 8 columns, 2 / 3 with 64 x 4 columns (256 threads:
+// twice as many independent barrier groups per CU) at >= 4 / >= 5 waves per SIMD, 4 64 x 8 at >= 6
+int rs_variant() {
+  static int variant = -1;
+  if (variant < 0) {
+    const char *e = std::getenv("NDSM_RS_VARIANT");
+    variant = e ? std::atoi(e) : 1;
+    if (variant < 0 || variant > 4) variant = 1;
+  }
+  return variant;
+}
+int rs_cj() { return (rs_variant() == 2 || rs_variant() == 3) ? 4 : 8; }
 
 }  // namespace
 
@@ -494,14 +508,14 @@ namespace ndsm {
 // footprint constants for the host-side coverage check (ndsmh_mg.f90)
 extern "C" void ndsmk_restrict_stream_tile(int *ci, int *cj, int *fx, int *fy, int *maxt) {
   *ci = kCI;
-  *cj = kCJ;
+  *cj = rs_cj();
   *fx = 2 * kCI + 6;
-  *fy = 2 * kCJ + 5;
+  *fy = 2 * rs_cj() + 5;
   *maxt = kMT;
 }
 
-template <typename TF>
-static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double *u_c) {
+template <typename TF, int CJ, int WPS, bool OLD>
+static int launch_rs_v(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double *u_c) {
   RSArgs a;
   for (int d = 0; d < 3; ++d) {
     a.nf[d] = x->nf[d];
@@ -517,20 +531,29 @@ static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
   a.c_beg = x->c_beg;
   a.c_cnt = x->c_cnt;
   a.nti = (x->nc[0] + kCI - 1) / kCI;
-  a.ntj = (x->nc[1] + kCJ - 1) / kCJ;
+  a.ntj = (x->nc[1] + CJ - 1) / CJ;
   const int tiles = a.nti * a.ntj;
-  // coarse planes per chunk: one workgroup per CU at a time (LDS), a chunk of kc coarse planes
-  // walks ~2 kc + 3 fine planes: minimise (rounds of workgroups) x (planes walked); the chunk's
-  // z tables must fit their LDS arrays (kc <= kKCMax)
-  static int occ = 0, occ_epoch = 0;
-  if (ndsm::first_in_epoch(occ_epoch)) {
-    int o = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, restrict_stream_k<TF, kCI, kCJ, kMT, kKCMax>, kCI * kCJ,
-                                                     sizeof(double) * 2 * (2 * kCI + 6) * (2 * kCJ + 5)) != hipSuccess || o < 1)
-      o = 1;
-    occ = o;
+  constexpr size_t lds_bytes =
+      sizeof(double) * (2 * (2 * kCI + 6) * (2 * CJ + 5) + (OLD ? 0 : (2 * kCI + 6)));
+  const bool odd = !OLD && (x->nf[0] & 1);
+  const void *kfn;
+  if constexpr (OLD) {
+    kfn = reinterpret_cast<const void *>(restrict_stream_k<TF, kCI, CJ, kMT, kKCMax>);
+  } else {
+    kfn = odd ? reinterpret_cast<const void *>(restrict_stream2_k<TF, kCI, CJ, kMT, kKCMax, WPS, true>)
+              : reinterpret_cast<const void *>(restrict_stream2_k<TF, kCI, CJ, kMT, kKCMax, WPS, false>);
   }
-  const int64_t slots = (int64_t)ndsm::cu_count() * occ;
+  // coarse planes per chunk: a chunk of kc coarse planes walks ~2 kc + 3 fine planes: minimise (rounds of
+  // workgroups at the kernel's occupancy) x (planes walked); the chunk's z tables must fit their LDS
+  // arrays (kc <= kKCMax)
+  static int occ[2] = {0, 0}, epoch[2] = {0, 0};
+  if (ndsm::first_in_epoch(epoch[odd])) {
+    NDSM_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int o = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kfn, kCI * CJ, lds_bytes) != hipSuccess || o < 1) o = 1;
+    occ[odd] = o;
+  }
+  const int64_t slots = (int64_t)ndsm::cu_count() * occ[odd];
   int kc = x->c_cnt < kKCMax ? x->c_cnt : kKCMax;
   int64_t best = -1;
   for (int c = 1; c <= x->c_cnt; ++c) {
@@ -549,31 +572,20 @@ static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
   a.nkc = (x->c_cnt + kc - 1) / kc;
   a.nwork = tiles * a.nkc;
   const int nblk = ((a.nwork + 7) / 8) * 8;
-  static int variant = -1;
-  if (variant < 0) {
-    const char *e = std::getenv("NDSM_RS_VARIANT");
-    variant = e ? std::atoi(e) : 1;
-  }
-  if (variant == 0) {
-    constexpr size_t lds_bytes = sizeof(double) * 2 * (2 * kCI + 6) * (2 * kCJ + 5);
-    auto kfn = restrict_stream_k<TF, kCI, kCJ, kMT, kKCMax>;
-    static int attr_epoch = 0;
-    if (ndsm::first_in_epoch(attr_epoch))
-      NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds_bytes));
-    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(kCI * kCJ), lds_bytes, stream(), r_f, rhs_c, u_c, a);
-  } else {
-    constexpr size_t lds_bytes = sizeof(double) * (2 * (2 * kCI + 6) * (2 * kCJ + 5) + (2 * kCI + 6));
-    auto kfn = (x->nf[0] & 1) ? restrict_stream2_k<TF, kCI, kCJ, kMT, kKCMax, 4, true>
-                              : restrict_stream2_k<TF, kCI, kCJ, kMT, kKCMax, 4, false>;
-    static int attr_epoch[2] = {0, 0};
-    if (ndsm::first_in_epoch(attr_epoch[x->nf[0] & 1]))
-      NDSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds_bytes));
-    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(kCI * kCJ), lds_bytes, stream(), r_f, rhs_c, u_c, a);
-  }
-  NDSM_LAUNCH_CHECK();
+  void *args[] = {(void *)&r_f, (void *)&rhs_c, (void *)&u_c, (void *)&a};
+  NDSM_HIP(hipLaunchKernel(kfn, dim3(nblk), dim3(kCI * CJ), args, lds_bytes, stream()));
   return 0;
+}
+
+template <typename TF>
+static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double *u_c) {
+  switch (rs_variant()) {
+    case 0: return launch_rs_v<TF, 8, 4, true>(x, r_f, rhs_c, u_c);
+    case 2: return launch_rs_v<TF, 4, 4, false>(x, r_f, rhs_c, u_c);
+    case 3: return launch_rs_v<TF, 4, 5, false>(x, r_f, rhs_c, u_c);
+    case 4: return launch_rs_v<TF, 8, 6, false>(x, r_f, rhs_c, u_c);
+    default: return launch_rs_v<TF, 8, 4, false>(x, r_f, rhs_c, u_c);
+  }
 }
 
 int launch_restrict_stream(const ndsmk_xfer *x, const double *r_f, double *rhs_c, double *u_c) {

@@ -426,11 +426,22 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     }
   }
   const size_t csz = PROL ? (size_t)pa.ncx * (size_t)pa.ncy : 0;
-  // coarse planes kcur, kcur+1 (and, prefetched, kcur+2) of this thread's coarse points
+  // coarse planes kcur, kcur+1 (and, prefetched, kcur+2) of this thread's coarse points.  The loads are
+  // UNCONDITIONAL, from a clamped address, and what lies outside the coarse window is replaced by zero
+  // when the value is consumed: a load under a branch (or a select right behind it) is waited for on the
+  // spot, and the wait that consumes an OLDER load turns into vmcnt(0) as soon as a conditional load may
+  // have been issued in between - either way every coarse plane costs a full memory round trip on the
+  // critical path of the plane loop (measured: 803 us per launch against 531 us without the correction).
+  auto prol_plane_ok = [&](int kc) { return kc >= pa.ck0 && kc < pa.ck0 + pa.nczw; };
   auto prol_load = [&](int kc, double *dst) {
+    const int kcl = min(max(kc, pa.ck0), pa.ck0 + pa.nczw - 1) - pa.ck0;
+    const double *pc = pa.uc + csz * (size_t)kcl;
 #pragma unroll
-    for (int c = 0; c < NCS; ++c)
-      dst[c] = (c_ok[c] && kc >= pa.ck0 && kc < pa.ck0 + pa.nczw) ? pa.uc[csz * (size_t)(kc - pa.ck0) + c_off[c]] : 0.0;
+    for (int c = 0; c < NCS; ++c) dst[c] = pc[c_off[c]];
+  };
+  auto prol_mask = [&](bool plane_ok, double *v) {
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) v[c] = (plane_ok && c_ok[c]) ? v[c] : 0.0;
   };
   // advance the rolling coarse planes to the bracket of fine plane kf and park its z-interpolated
   // coarse plane in LDS (the caller puts a barrier between this and prol_corr)
@@ -438,26 +449,51 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   // iteration costs its whole latency on every plane)
   int zt_kc = 0;
   double zt_wl = 0.0, zt_wh = 0.0;
+  // the z tables of the chunk's planes sit in LDS (a lookup is then an LDS read; from global memory the
+  // compiler turns the uniform value into a scalar right at the load and waits for it there - one memory
+  // round trip per plane); chunks taller than the LDS table keep the global lookups
+  constexpr int ZT = PROL ? 160 : 1;
+  __shared__ int s_zkc[ZT];
+  __shared__ double s_zwl[ZT], s_zwh[ZT];
+  const bool zt_lds = PROL && (ke - ks + 4 <= ZT);
+  if (PROL && zt_lds) {
+    for (int t = tid; t < ke - ks + 4; t += NT) {
+      const int kq = min(max(ks + t + pa.fk0, 0), pa.nzf - 1);   // table index = global fine plane
+      s_zkc[t] = pa.plo[2][kq];
+      s_zwl[t] = pa.pwl[2][kq];
+      s_zwh[t] = pa.pwh[2][kq];
+    }
+    __syncthreads();
+  }
   auto prol_ztab = [&](int kf) {
-    const int kq = min(max(kf + pa.fk0, 0), pa.nzf - 1);   // table index = global fine plane
-    zt_kc = pa.plo[2][kq];
-    zt_wl = pa.pwl[2][kq];
-    zt_wh = pa.pwh[2][kq];
+    if (zt_lds) {
+      zt_kc = s_zkc[kf - ks];
+      zt_wl = s_zwl[kf - ks];
+      zt_wh = s_zwh[kf - ks];
+    } else {
+      const int kq = min(max(kf + pa.fk0, 0), pa.nzf - 1);
+      zt_kc = pa.plo[2][kq];
+      zt_wl = pa.pwl[2][kq];
+      zt_wh = pa.pwh[2][kq];
+    }
   };
   auto prol_stage = [&](int kf) {
     double *const czt = czt0 + (kf & 1) * (CW * CH);
     const int kc = zt_kc;
     const double wlz = zt_wl, whz = zt_wh;
     prol_ztab(kf + 1);
-    if (kc > kcur) {  // the bracket moves up by at most one coarse plane per fine plane
+    // the bracket moves up by at most one coarse plane per fine plane.  c_nx was requested one stage
+    // ago at the latest; it is consumed (masked) here EVERY stage - taken over when the bracket moves,
+    // dropped otherwise - and requested again right away, for the plane the next move will need
+    const bool adv = kc > kcur;
+    prol_mask(prol_plane_ok(kcur + 2), c_nx);
 #pragma unroll
-      for (int c = 0; c < NCS; ++c) {
-        c_lo[c] = c_hi[c];
-        c_hi[c] = c_nx[c];
-      }
-      kcur = kc;
-      prol_load(kcur + 2, c_nx);
+    for (int c = 0; c < NCS; ++c) {
+      c_lo[c] = adv ? c_hi[c] : c_lo[c];
+      c_hi[c] = adv ? c_nx[c] : c_hi[c];
     }
+    kcur = adv ? kc : kcur;
+    prol_load(kcur + 2, c_nx);
 #pragma unroll
     for (int c = 0; c < NCS; ++c) {
       const int idx = tid + NT * c;
@@ -503,6 +539,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       prol_load(kcur, c_lo);
       prol_load(kcur + 1, c_hi);
       prol_load(kcur + 2, c_nx);
+      prol_mask(prol_plane_ok(kcur), c_lo);
+      prol_mask(prol_plane_ok(kcur + 1), c_hi);
       prol_stage(ks);
       if (ks + 1 <= ke) prol_stage(ks + 1);
       __syncthreads();
@@ -530,7 +568,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     // byte offset of the LDS buffer of plane k - d, -1 <= d <= NSTG
     auto bufoff = [&](int d) {
       int b;
-      if (RES) {
+      if ((NSTG & (NSTG - 1)) != 0) {   // pipeline depth not a power of two (residual stage, three sweeps)
         b = kb - d;
         b = b < 0 ? b + NSTG : b;
         b = b >= NSTG ? b - NSTG : b;
@@ -986,11 +1024,19 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
       return 0;
     }
   }
+  // THREE sweeps per pass were tried and are not built: six LDS planes force a narrower tile (72 x 46 or
+  // 88 x 38 owned 60 x 34 / 76 x 26: 1.6-1.7x redundant stage work instead of 1.45x) and the pass turns
+  // LDS / issue bound - measured at 512^3 (Laplace): 1075-1120 us per three-sweep pass against 553 us per
+  // two-sweep pass, i.e. 358 against 282 us per sweep; same bits (scripts/time_s3.py, round 2).
   if (two) {
     if constexpr (ODD) {   // the tuning alternates and the level-1 symbol exist for even nx only
       rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 0, false, true>(g, u, uout, rhs, tgt));
     } else {
-      switch (cfg[0]) {
+      // levels of a few million points (the 128^3 level of a 512^3 hierarchy) do not fill the chip with
+      // 136 x 30 tiles: the 72 x 28 tile (512 threads) gives four times the workgroups - measured 77 against
+      // 98 us per five sweeps at 128^3, 293 against 280 us at 256^3 (scripts/time_tail.py)
+      const int two_cfg = cfg[0] ? cfg[0] : (npts < (int64_t)6 * 1024 * 1024 && !slab ? 5 : 0);
+      switch (two_cfg) {
         case 3: rc = launch_cfg<T, 2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;
         case 5: rc = launch_cfg<T, 2, 72, 28, 512, 4>(g, u, uout, rhs, tgt); break;
         default:

@@ -142,17 +142,15 @@ int launch_tile(const ndsmk_grid &g, const double *u, double *uout, const double
 
 namespace ndsm {
 
-// levels this kernel is the default for: more points than the single-workgroup kernel takes, fewer than
-// NDSM_TILE_MAX (default 4 M: the 128^3 level of a 512^3 hierarchy included)
+// levels this kernel serves: more points than the single-workgroup kernel takes, at most NDSM_TILE_MAX
+// (environment, or ndsmk_debug_tile_max at run time)
+static long long g_tile_max = -1;
 bool tile_smoother_applies(const ndsmk_grid &g) {
-  static long long tmax = -1;
+  long long &tmax = g_tile_max;
   if (tmax < 0) {
     const char *e = std::getenv("NDSM_TILE_MAX");
-    tmax = e ? std::atoll(e) : 4ll * 1024 * 1024;
+    tmax = e ? std::atoll(e) : 0;   // OFF by default: measured slower than the colour passes / the streaming kernel so far
   }
-  static int off = -1;
-  if (off < 0) off = std::getenv("NDSM_NO_TILE") ? 1 : 0;   // A/B timing
-  if (off) return false;
   const long long npts = (long long)g.n[0] * g.n[1] * g.n[2];
   return g.ndim == 3 && !g.all_neumann && g.k0 == 0 && g.zown0 == 0 && g.zown1 == g.n[2] && g.nzg == g.n[2] &&
          npts > 4096 && npts <= tmax && g.n[0] >= 4 && g.n[1] >= 4 && g.n[2] >= 4;
@@ -183,3 +181,9 @@ int launch_rbgs3_tile(const ndsmk_grid &g, const double *u, double *uout, const 
 }
 
 }  // namespace ndsm
+
+// tests / tuning: levels of up to `max_points` points take the tile smoother (0: none)
+extern "C" int ndsmk_debug_tile_max(long long max_points) {
+  ndsm::g_tile_max = max_points < 0 ? 0 : max_points;
+  return 0;
+}
