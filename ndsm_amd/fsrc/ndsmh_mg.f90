@@ -570,13 +570,22 @@ contains
 
     ! ascend: smooth the coarse problem, interpolate + correct, post-smooth
     ! (coarse_to_fine, :593-684)
+    ! The reference smooths level l-1 ms times after the correction (:672-675) and, one level up the
+    ! loop, ms times again before interpolating it further (:651-654): 2 ms consecutive sweeps of one
+    ! array.  They are issued as ONE relax call here (five two-sweep passes instead of 2+2+1 twice on the
+    ! streamed levels, one launch instead of two on the single-workgroup levels) - the same sweeps in the
+    ! same order.
+    rc = mg_op(s, MG_OP_RELAX, s%ngrids, s%ms); if (rc /= 0) return
     do l = s%ngrids, ltop + 1, -1
-      rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
       if (l - 1 == 1 .and. s%track) then      ! interpolate + correct + post-smooth as one call
         rc = relax_tracked(s, s%ms, .false., .true., prolong=.true.); if (rc /= 0) return
       else
         rc = mg_op(s, MG_OP_PROLONG, l - 1, 1); if (rc /= 0) return
-        rc = mg_op(s, merge(MG_OP_RELAX_LAST, MG_OP_RELAX, l - 1 == 1), l - 1, s%ms); if (rc /= 0) return
+        if (l - 1 == ltop) then
+          rc = mg_op(s, merge(MG_OP_RELAX_LAST, MG_OP_RELAX, l - 1 == 1), l - 1, s%ms); if (rc /= 0) return
+        else
+          rc = mg_op(s, MG_OP_RELAX, l - 1, 2 * s%ms); if (rc /= 0) return
+        end if
       end if
     end do
     rc = 0

@@ -455,6 +455,8 @@ contains
         ! hierarchy returns after the solves (the peak is then A + one hierarchy, as before)
         rc = ndsmk_mem_info(fr, tot); if (rc /= 0) return
         resident = fr >= 3_c_size_t * nb + ishft(1_c_size_t, 31)
+        call get_environment_variable("NDSM_HIP_LEAN", status=st)      ! testing: take the small-HBM sequence
+        if (st == 0) resident = .false.
         if (resident) then
           rc = ndsmk_alloc(ctx%dB, 3_c_size_t * nb); if (rc /= 0) return
         end if

@@ -1289,3 +1289,80 @@ def test_tile_smoother_bitwise(hip, port, ns):
         S.close()
     finally:
         L.ndsm_hip_debug_tile_max(0)
+
+
+@pytest.mark.gpu
+def test_baseline_config4_full_grid_mixed_component(hip):
+    """BASELINE config[4]'s grid at FULL size - 2048 x 2048 x 1024 = 2^32 points, 32 GiB per fp64 array - and
+    in its precision mode (fp32 smoother / fp64 residual): two solve-loop cycles of ONE component (Ay's
+    boundary letters) in the mixed-precision mode, single domain against the 8-slab loop-back world - du
+    history and solution bit for bit.  (The vector-potential driver around it needs A, B and a hierarchy at
+    once, 3 x 32 + 3 x 32 + ~180 GiB: that is what the eight GPUs are for; on one GPU the per-component
+    solve is the part that fits.)  Needs ~130 GiB of host memory and ~230 GiB of HBM."""
+    with open("/proc/meminfo") as f:
+        avail = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 2**20
+    if avail < 160:
+        pytest.skip(f"only {avail:.0f} GiB of host memory available")
+    ns = [2048, 2048, 1024]
+    dx = 1.0 / (ns[0] - 1)
+    mesh = [np.arange(n) * dx for n in ns]
+    rng = np.random.default_rng(14)
+    plane = rng.uniform(-1, 1, (ns[1], ns[0]))
+    zf = np.cos(np.arange(ns[2]) * 0.37) + 0.01 * np.arange(ns[2])
+    u = np.empty((ns[2], ns[1], ns[0]))
+    for k in range(ns[2]):
+        np.multiply(plane, zf[k], out=u[k])
+        u[k, (k * 7) % ns[1]] += 0.5
+    try:
+        S = hip.MGSolver(ns, mesh, "DNDDND")
+    except hip.NdsmHipError as exc:
+        pytest.skip(f"the single-domain hierarchy does not fit this GPU: {exc}")
+    assert S.set_precision(1)
+    S.upload(1, hip.BUF_U, u)
+    S.zero_rhs()
+    ie, du_s, nc, hs = S.solve(vc_tol=0.0, nmax=2, hist_len=4)
+    a = S.download(1, hip.BUF_U)
+    S.close()
+    W = hip.World(ns, mesh, "DNDDND", 8)
+    assert W.set_precision(1)
+    W.upload(hip.BUF_U, u)
+    del u
+    W.zero_rhs()
+    ie, du_w, nc, hw = W.solve(vc_tol=0.0, nmax=2, hist_len=4)
+    b = W.download(hip.BUF_U)
+    W.close()
+    assert list(hs) == list(hw) and len(hs) == 2 and hs[1] < hs[0]
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns", ([5, 4, 6], [17, 23, 19], [64, 20, 33]), ids=_tag)
+def test_vecpot_paths_small_and_ragged_shapes(hip, port, ns):
+    """the device face phase, the cached context and the small-HBM sequence (NDSM_HIP_LEAN: B takes the
+    memory of the destroyed 3-D hierarchy) on tiny, odd and anisotropic boxes: all three return the bits
+    of the host face phase, and the oracle's pipeline agrees within the stated bound"""
+    import ndsm_amd
+    x, y, z, _A1, b = analytic_case(ns)
+    b = b + 0.1 * np.random.default_rng(3).uniform(-1, 1, b.shape)
+    os.environ["NDSM_HIP_HOST_FACES"] = "1"
+    os.environ["NDSM_HIP_NO_CACHE"] = "1"
+    try:
+        i0, A0, B0 = ndsm_amd.vector_potential(x, y, z, b.copy())
+    finally:
+        os.environ.pop("NDSM_HIP_HOST_FACES", None)
+        os.environ.pop("NDSM_HIP_NO_CACHE", None)
+    i1, A1, B1 = ndsm_amd.vector_potential(x, y, z, b.copy())
+    os.environ["NDSM_HIP_LEAN"] = "1"
+    try:
+        i2, A2, B2 = ndsm_amd.vector_potential(x, y, z, b.copy())
+        i3, A3, B3 = ndsm_amd.vector_potential(x, y, z, b.copy())
+    finally:
+        os.environ.pop("NDSM_HIP_LEAN", None)
+    i4, A4, B4 = ndsm_amd.vector_potential(x, y, z, b.copy())
+    for ie, A, B in ((i1, A1, B1), (i2, A2, B2), (i3, A3, B3), (i4, A4, B4)):
+        assert ie == i0 and np.array_equal(A, A0) and np.array_equal(B, B0)
+    ie, Ao, Bo, _io, _ro = port.vector_potential(x, y, z, b)
+    assert ie == i0
+    h = x[1] - x[0]
+    assert np.abs(A0 - Ao).max() <= 1e-12 * max(np.abs(Ao).max(), 1e-300)
+    assert np.abs(B0 - Bo).max() <= 1e-12 * max(np.abs(Ao).max(), 1e-300) * 4 / h
