@@ -1,0 +1,25 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one go (GPU box, from the repo root):
+#   scripts/collect_round_profiles.sh r02     -> gpurun_out/profiles_r02/*  (copy what is to be judged into profiles/)
+set -e
+tag=${1:-rXX}
+out=gpurun_out/profiles_$tag
+rm -rf $out; mkdir -p $out
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e \
+   > $out/${tag}_bench_under_rocprof.json 2> $out/bench_prof.err
+cp $out/prof/*/b_kernel_stats.csv $out/${tag}_kernel_stats.csv 2>/dev/null || cp $out/prof/b_kernel_stats.csv $out/${tag}_kernel_stats.csv
+echo "stats done"
+python3 bench.py > $out/${tag}_bench.json 2> $out/bench.err
+echo "bench done"
+bash scripts/collect_traffic.sh > $out/traffic.log 2>&1 || true
+cp profiles/traffic_latest.json $out/traffic_latest.json
+echo "traffic done"
+scripts/pmc_kernel.sh ${tag}_rs2 restrict_stream2_k -- scripts/time_transfer.py 512 > /dev/null
+cp gpurun_out/pmc_${tag}_rs2/summary.txt $out/${tag}_restrict_stream2_counters.txt
+NDSM_RS_VARIANT=0 scripts/pmc_kernel.sh ${tag}_rs0 restrict_stream_k -- scripts/time_transfer.py 512 > /dev/null
+cp gpurun_out/pmc_${tag}_rs0/summary.txt $out/${tag}_restrict_stream_v0_counters.txt
+echo "counters done"
+python3 scripts/time_pipeline.py 512 > $out/pipeline.log 2>&1 || true
+python3 scripts/time_tail.py 512 > $out/${tag}_levels.txt 2>&1 || true
+ls -la $out
