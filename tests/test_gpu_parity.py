@@ -1366,3 +1366,29 @@ def test_vecpot_paths_small_and_ragged_shapes(hip, port, ns):
     h = x[1] - x[0]
     assert np.abs(A0 - Ao).max() <= 1e-12 * max(np.abs(Ao).max(), 1e-300)
     assert np.abs(B0 - Bo).max() <= 1e-12 * max(np.abs(Ao).max(), 1e-300) * 4 / h
+
+
+@pytest.mark.gpu
+def test_correction_launch_with_one_tall_chunk(hip, port):
+    """the launch that interpolates the coarse-grid correction while it loads (MODE 3) keeps the z tables of
+    its chunk in LDS; a chunk taller than that table (a workgroup walking the whole of a tall grid, as on the
+    2048 x 2048 x 1024 grid) reads them from global memory instead: forced here with one work item per tile
+    on a 96 x 64 x 420 grid, two solve-loop cycles against the oracle"""
+    L = hip.load_library()
+    ns = [96, 64, 420]
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u0 = rand_field(shp, 31)
+    ie2, u2, du2, h2, nc2, _sw = port.solve_bvp(u0.copy(), np.zeros(shp), mesh, "NDDNDD", ms=5, nmax=2, hist_len=4)
+    L.ndsm_hip_debug_fused_cfg(0, 0, 0, 1, -1)        # one work item per tile: a single chunk of 420 planes
+    try:
+        S = hip.MGSolver(ns, mesh, "NDDNDD", ms=5)
+        S.zero_rhs()
+        S.upload(1, hip.BUF_U, u0)
+        ie, du, nc, h = S.solve(vc_tol=1e-10, nmax=2, hist_len=4)
+        got = S.download(1, hip.BUF_U)
+        S.close()
+    finally:
+        L.ndsm_hip_debug_fused_cfg(0, 0, 0, 0, -1)
+    assert nc == nc2 == 2 and list(h) == list(h2[:2])
+    assert np.array_equal(got, u2)
