@@ -271,7 +271,9 @@ __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const TF *__restrict
 //   * the x tap count is made wave-uniform (the wave's maximum) and the weights of the taps a column does
 //     not have are exact zeros: w * f = +-0 and x + (+-0) = x bit for bit (the running sum starts at +0
 //     and can never become -0), so the padded taps change nothing and the loops need no exec masking.
-//     LDS is zero-filled once so that a padded tap never meets an uninitialised word.
+//     LDS is zero-filled once so that a padded tap never meets an uninitialised word.  (Holds for finite
+//     data: 0 * Inf is NaN, so a residual that already contains Inf / NaN - a diverged solve - can poison a
+//     coarse point one column earlier than in the reference.)
 // Same tap order and weight chain: bit-identical (tests/test_gpu_parity.py::test_transfer3d_bitwise,
 // test_large_level_kernels_bitwise, the V-cycle tests).
 template <typename TF, int CI, int CJ, int MT, int KCMAX, int WPS, bool ODDX>
