@@ -133,3 +133,32 @@ def test_python_loader_signature_matches_reference():
     got = [(p.name, p.default) for p in sig.parameters.values()]
     assert got[:len(want)] == want
     assert {"libname", "libpath", "debug"} <= set(sig.parameters)
+
+
+def test_additive_entry_points_fail_cleanly_without_a_gpu(lib):
+    """round-2 additions on a box without a GPU: error codes, never a crash, never a computed result"""
+    if lib.ndsm_hip_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    n = 8
+    x = np.linspace(0, 1, n)
+    ns4 = np.array([n, n, n, 3], dtype=np.intc)
+    h = ctypes.c_void_p()
+    lib.ndsm_hip_vecpot_create.argtypes = [ip, dp, dp, dp, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    rc = lib.ndsm_hip_vecpot_create(ns4.ctypes.data_as(ip), x.ctypes.data_as(dp), x.ctypes.data_as(dp),
+                                    x.ctypes.data_as(dp), 0, ctypes.byref(h))
+    assert rc == 9001 and not h.value
+    assert lib.ndsm_hip_vecpot_destroy(None) == 0
+    r, m = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert lib.ndsm_hip_dist_info(ctypes.byref(r), ctypes.byref(m)) == 0 and (r.value, m.value) == (0, 0)
+    assert lib.ndsm_hip_dist_selftest(16) != 0                  # no runtime, no communicator
+    assert lib.ndsm_hip_shutdown() == 0 and lib.ndsm_hip_shutdown() == 0
+    assert lib.ndsm_hip_debug_fused_cfg(0, 0, 0, 0, -1) == 0
+    lib.ndsm_hip_debug_tile_max.argtypes = [ctypes.c_longlong]
+    assert lib.ndsm_hip_debug_tile_max(0) == 0
+    p = ctypes.c_void_p()
+    lib.ndsm_hip_device_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+    assert lib.ndsm_hip_device_alloc(1024, ctypes.byref(p)) == 9001 and not p.value
+    import ndsm_amd
+    with pytest.raises(ndsm_amd.NdsmHipError):
+        ndsm_amd.VecPot(x, x, x)
