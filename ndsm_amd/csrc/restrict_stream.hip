@@ -276,7 +276,7 @@ __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const TF *__restrict
 //     coarse point one column earlier than in the reference.)
 // Same tap order and weight chain: bit-identical (tests/test_gpu_parity.py::test_transfer3d_bitwise,
 // test_large_level_kernels_bitwise, the V-cycle tests).
-template <typename TF, int CI, int CJ, int MT, int KCMAX, int WPS, bool ODDX>
+template <typename TF, int CI, int CJ, int MT, int KCMAX, int WPS, bool ODDX, int DEPTH = 3>
 __global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__restrict__ f, double *__restrict__ rhs_c,
                                                                   double *__restrict__ u_c, RSArgs a) {
   constexpr int NT = CI * CJ;
@@ -463,45 +463,56 @@ __global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__re
     while (Klo < Ke && __builtin_amdgcn_readfirstlane(s_z0[Klo - Ks] + s_nk[Klo - Ks]) - 1 <= k) ++Klo;
   };
 
-  // ---- prologue: plane kA into LDS buffer 0, planes kA+1, kA+2 on their way ----
-  d2 r0[NS], r1[NS], r2[NS];
+  // ---- prologue: plane kA into LDS buffer 0, planes kA+1 (, kA+2) on their way ----
+  static_assert(DEPTH == 2 || DEPTH == 3, "planes in flight");
+  d2 r0[NS], r1[NS], r2[DEPTH == 3 ? NS : 1];
   __syncthreads();  // the zero fill is complete
   load_plane(kA, r0);
   load_plane(kA + 1, r1);
-  load_plane(kA + 2, r2);
+  if constexpr (DEPTH == 3) load_plane(kA + 2, r2);
   store_plane(lds, r0, true);
   __syncthreads();  // also publishes the z tables
 
-  // one plane-step: request plane k+3 into the slot plane k came from, consume plane k, move plane k+1
+  // one plane-step: request plane k+DEPTH into the slot plane k came from, consume plane k, move plane k+1
   // from its slot into the other LDS buffer
   auto step = [&](int k, d2(&slot_k)[NS], const d2(&slot_k1)[NS]) {
-    load_plane(k + 3, slot_k);
+    load_plane(k + DEPTH, slot_k);
     consume(k, lds + ((k - kA) & 1) * PLANE);
     store_plane(lds + ((k + 1 - kA) & 1) * PLANE, slot_k1, k + 1 <= kB);
     __syncthreads();
   };
-  for (int k = kA; k <= kB; k += 3) {
-    step(k, r0, r1);
-    if (k + 1 <= kB) step(k + 1, r1, r2);
-    if (k + 2 <= kB) step(k + 2, r2, r0);
+  if constexpr (DEPTH == 3) {
+    for (int k = kA; k <= kB; k += 3) {
+      step(k, r0, r1);
+      if (k + 1 <= kB) step(k + 1, r1, r2);
+      if (k + 2 <= kB) step(k + 2, r2, r0);
+    }
+  } else {
+    for (int k = kA; k <= kB; k += 2) {
+      step(k, r0, r1);
+      if (k + 1 <= kB) step(k + 1, r1, r0);
+    }
   }
 }
 
 constexpr int kCI = 64, kMT = 5, kKCMax = 64;
 
 // which form of the kernel runs (NDSM_RS_VARIANT; tuning aid): 0 the first kernel (64 x 8 coarse columns,
-// one plane of prefetch), 1 restrict_stream2_k with 64 x 8 columns, 2 / 3 with 64 x 4 columns (256 threads:
-// twice as many independent barrier groups per CU) at >= 4 / >= 5 waves per SIMD, 4 64 x 8 at >= 6
+// one plane of prefetch: 432 us at 512^3), 1 restrict_stream2_k with 64 x 8 columns and three planes in flight
+// (388-393 us, the default); with two planes in flight: 2 = 64 x 4 columns (256 threads: twice as many independent
+// barrier groups per CU; 391 us), 5 = 64 x 8 columns (383 us).  Forcing three workgroups per CU (<= 85 VGPRs)
+// spills and takes 816-1400 us: not built.  Neither the prefetch depth nor the number of barrier groups moves
+// the kernel any further: a plane-step takes 2.9 us against 2.1 us of HBM time for its 11.5 MB (chip-wide).
 int rs_variant() {
   static int variant = -1;
   if (variant < 0) {
     const char *e = std::getenv("NDSM_RS_VARIANT");
     variant = e ? std::atoi(e) : 1;
-    if (variant < 0 || variant > 4) variant = 1;
+    if (variant != 0 && variant != 2 && variant != 5) variant = 1;
   }
   return variant;
 }
-int rs_cj() { return (rs_variant() == 2 || rs_variant() == 3) ? 4 : 8; }
+int rs_cj() { return rs_variant() == 2 ? 4 : 8; }
 
 }  // namespace
 
@@ -516,7 +527,7 @@ extern "C" void ndsmk_restrict_stream_tile(int *ci, int *cj, int *fx, int *fy, i
   *maxt = kMT;
 }
 
-template <typename TF, int CJ, int WPS, bool OLD>
+template <typename TF, int CJ, int WPS, bool OLD, int DEPTH = 3>
 static int launch_rs_v(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double *u_c) {
   RSArgs a;
   for (int d = 0; d < 3; ++d) {
@@ -542,8 +553,8 @@ static int launch_rs_v(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
   if constexpr (OLD) {
     kfn = reinterpret_cast<const void *>(restrict_stream_k<TF, kCI, CJ, kMT, kKCMax>);
   } else {
-    kfn = odd ? reinterpret_cast<const void *>(restrict_stream2_k<TF, kCI, CJ, kMT, kKCMax, WPS, true>)
-              : reinterpret_cast<const void *>(restrict_stream2_k<TF, kCI, CJ, kMT, kKCMax, WPS, false>);
+    kfn = odd ? reinterpret_cast<const void *>(restrict_stream2_k<TF, kCI, CJ, kMT, kKCMax, WPS, true, DEPTH>)
+              : reinterpret_cast<const void *>(restrict_stream2_k<TF, kCI, CJ, kMT, kKCMax, WPS, false, DEPTH>);
   }
   // coarse planes per chunk: a chunk of kc coarse planes walks ~2 kc + 3 fine planes: minimise (rounds of
   // workgroups at the kernel's occupancy) x (planes walked); the chunk's z tables must fit their LDS
@@ -583,9 +594,8 @@ template <typename TF>
 static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double *u_c) {
   switch (rs_variant()) {
     case 0: return launch_rs_v<TF, 8, 4, true>(x, r_f, rhs_c, u_c);
-    case 2: return launch_rs_v<TF, 4, 4, false>(x, r_f, rhs_c, u_c);
-    case 3: return launch_rs_v<TF, 4, 5, false>(x, r_f, rhs_c, u_c);
-    case 4: return launch_rs_v<TF, 8, 6, false>(x, r_f, rhs_c, u_c);
+    case 2: return launch_rs_v<TF, 4, 4, false, 2>(x, r_f, rhs_c, u_c);
+    case 5: return launch_rs_v<TF, 8, 4, false, 2>(x, r_f, rhs_c, u_c);
     default: return launch_rs_v<TF, 8, 4, false>(x, r_f, rhs_c, u_c);
   }
 }
