@@ -28,6 +28,7 @@ struct RSArgs {
   double w2[3];
   int f_k0, c_k0, c_beg, c_cnt;
   int nti, ntj, nkc, kc, nwork;
+  int probe;   // tuning aid (NDSM_RS_PROBE): 1 = stream the planes but skip the tap arithmetic, 2 = arithmetic without the loads
 };
 
 struct d2 {
@@ -476,8 +477,8 @@ __global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__re
   // one plane-step: request plane k+DEPTH into the slot plane k came from, consume plane k, move plane k+1
   // from its slot into the other LDS buffer
   auto step = [&](int k, d2(&slot_k)[NS], const d2(&slot_k1)[NS]) {
-    load_plane(k + DEPTH, slot_k);
-    consume(k, lds + ((k - kA) & 1) * PLANE);
+    if (a.probe != 2) load_plane(k + DEPTH, slot_k);
+    if (a.probe != 1) consume(k, lds + ((k - kA) & 1) * PLANE);
     store_plane(lds + ((k + 1 - kA) & 1) * PLANE, slot_k1, k + 1 <= kB);
     __syncthreads();
   };
@@ -502,7 +503,10 @@ constexpr int kCI = 64, kMT = 5, kKCMax = 64;
 // (388-393 us, the default); with two planes in flight: 2 = 64 x 4 columns (256 threads: twice as many independent
 // barrier groups per CU; 391 us), 5 = 64 x 8 columns (383 us).  Forcing three workgroups per CU (<= 85 VGPRs)
 // spills and takes 816-1400 us: not built.  Neither the prefetch depth nor the number of barrier groups moves
-// the kernel any further: a plane-step takes 2.9 us against 2.1 us of HBM time for its 11.5 MB (chip-wide).
+// the kernel any further, because it is bound by the tap arithmetic, not by memory: with the arithmetic skipped
+// the same launch streams its 1.28 GB in 174-190 us (6.7-7.3 TB/s), with the loads skipped the arithmetic alone
+// takes 365 us (NDSM_RS_PROBE=1 / 2) - fp64 multiply / add chains at four waves per SIMD (126 VGPRs; the
+// compiler keeps a plane's 16-25 tap values and weight prefixes in registers) run the SIMDs at ~50 %.
 int rs_variant() {
   static int variant = -1;
   if (variant < 0) {
@@ -584,6 +588,9 @@ static int launch_rs_v(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
   a.kc = kc;
   a.nkc = (x->c_cnt + kc - 1) / kc;
   a.nwork = tiles * a.nkc;
+  static int probe = -1;
+  if (probe < 0) probe = std::getenv("NDSM_RS_PROBE") ? std::atoi(std::getenv("NDSM_RS_PROBE")) : 0;
+  a.probe = probe;
   const int nblk = ((a.nwork + 7) / 8) * 8;
   void *args[] = {(void *)&r_f, (void *)&rhs_c, (void *)&u_c, (void *)&a};
   NDSM_HIP(hipLaunchKernel(kfn, dim3(nblk), dim3(kCI * CJ), args, lds_bytes, stream()));
