@@ -25,6 +25,7 @@ struct Dist {
   int rank = 0, size = 1;
   ncclComm_t comm = nullptr;
   double *d_red = nullptr;  // 2 doubles
+  int group_depth = 0;      // ncclGroupStart calls not yet matched (ndsmk_dist_group_abort closes them)
 };
 Dist g_d;
 
@@ -113,11 +114,22 @@ int ndsmk_dist_size(void) { return g_d.up ? g_d.size : 1; }
 int ndsmk_dist_group_start(void) {
   NDSM_CHECK_ARG(g_d.up);
   NDSM_NCCL(ncclGroupStart());
+  ++g_d.group_depth;
   return 0;
 }
 int ndsmk_dist_group_end(void) {
   NDSM_CHECK_ARG(g_d.up);
+  if (g_d.group_depth > 0) --g_d.group_depth;
   NDSM_NCCL(ncclGroupEnd());
+  return 0;
+}
+// error paths: close whatever group an aborted sequence left open (the calls collected so far are
+// issued; the caller is about to report its error anyway) - an open group would swallow every later call
+int ndsmk_dist_group_abort(void) {
+  while (g_d.up && g_d.group_depth > 0) {
+    --g_d.group_depth;
+    (void)ncclGroupEnd();
+  }
   return 0;
 }
 

@@ -39,6 +39,7 @@ module ndsmh_world
   public :: mg_world, world_create, world_destroy, world_vcycle, world_solve, world_relax
   public :: world_upload, world_download, world_plan_only, world_set_params, world_dist_levels
   public :: ndsmk_dist_group_start, ndsmk_dist_group_end, ndsmk_dist_send, ndsmk_dist_recv   ! for ndsmh_wvecpot
+  public :: ndsmk_dist_group_abort
   public :: world_set_precision
 
   interface
@@ -51,6 +52,10 @@ module ndsmh_world
       integer(c_int) :: n
     end function
     function ndsmk_dist_group_start() bind(c, name="ndsmk_dist_group_start") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
+    function ndsmk_dist_group_abort() bind(c, name="ndsmk_dist_group_abort") result(rc)
       import :: c_int
       integer(c_int) :: rc
     end function

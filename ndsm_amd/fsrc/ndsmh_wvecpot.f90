@@ -279,6 +279,7 @@ contains
     call say(me, "Deallocate memory...")
 
 900 continue
+    if (rc /= 0) i = ndsmk_dist_group_abort()      ! an error inside a send/recv group: close it before leaving
     if (livew) call world_destroy(w)
     i = ndsmk_free(dA); i = ndsmk_free(dB); i = ndsmk_free(dmesh); i = ndsmk_free(dpack)
 
