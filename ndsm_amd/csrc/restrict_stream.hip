@@ -507,6 +507,9 @@ constexpr int kCI = 64, kMT = 5, kKCMax = 64;
 // the same launch streams its 1.28 GB in 174-190 us (6.7-7.3 TB/s), with the loads skipped the arithmetic alone
 // takes 365 us (NDSM_RS_PROBE=1 / 2) - fp64 multiply / add chains at four waves per SIMD (126 VGPRs; the
 // compiler keeps a plane's 16-25 tap values and weight prefixes in registers) run the SIMDs at ~50 %.
+// Also tried: a straight-line 4 x 4 tap block (no uniform branch around each tap, so that the LDS reads of a
+// row overlap) with the y weights in scalar registers and the prefix re-formed per tap to stay inside 128
+// VGPRs - 455 us (arithmetic alone 430): the 25 % more multiplications cost more than the branches did.
 int rs_variant() {
   static int variant = -1;
   if (variant < 0) {
