@@ -157,7 +157,16 @@ def end_to_end(L, n, pretouch=True):
         if ierr != 0:
             return {"error": f"ndsm_vector_solve returned {ierr}"}
         ncyc = int(ioptc[L.get_iopt_ncyc_out()])
-    return {"e2e_s": times[0], "e2e_second_call_s": times[1], "ncycles_last_3d_solve": ncyc,
+    py_s = None
+    if pretouch:
+        # the reference-compatible Python front end on top (ndsm.py's calling convention: fresh result arrays)
+        import ndsm_amd
+        del A, B
+        t0 = time.perf_counter()
+        _ie, _A, _B = ndsm_amd.vector_potential(x, y, z, b1)
+        py_s = time.perf_counter() - t0
+        del _A, _B
+    return {"e2e_s": times[0], "e2e_second_call_s": times[1], "python_front_end_s": py_s, "ncycles_last_3d_solve": ncyc,
             "what": f"ndsm_vector_solve at {n}^3, host buffers in and out (the initial guess A up unless it is all zero, 6 GiB of "
                     "A and B down over PCIe, six 2-D + three 3-D solves to vc_tol=1e-10, flux balance, curl); second call = same mesh again"}
 

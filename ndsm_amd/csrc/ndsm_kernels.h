@@ -96,6 +96,7 @@ int ndsmk_timer_stop(double *ms);           /* blocking; elapsed between start a
  * main stream has passed the point of the call.  Tickets die in ndsmk_bg_drain (blocking, first error). */
 int ndsmk_bg_upload_unless_zero(const void *h_src, void *d_dst, size_t bytes, int *ticket);
 int ndsmk_bg_download(void *h_dst, const void *d_src, size_t bytes, int *ticket);
+int ndsmk_bg_first_touch(void *h_dst, size_t bytes, int *ticket);   /* h_dst will be overwritten completely */
 int ndsmk_bg_wait(int ticket, int *flag);
 int ndsmk_bg_drain(void);
 int ndsmk_host_alloc(void **p, size_t bytes);               /* pinned */

@@ -314,6 +314,13 @@ module ndsmh_iface
       integer(c_int), intent(out) :: ticket
       integer(c_int) :: rc
     end function
+    function ndsmk_bg_first_touch(h_dst, bytes, ticket) bind(c, name="ndsmk_bg_first_touch") result(rc)
+      import :: c_ptr, c_size_t, c_int
+      type(c_ptr), value :: h_dst
+      integer(c_size_t), value :: bytes
+      integer(c_int), intent(out) :: ticket
+      integer(c_int) :: rc
+    end function
     function ndsmk_bg_wait(ticket, flag) bind(c, name="ndsmk_bg_wait") result(rc)
       import :: c_int
       integer(c_int), value :: ticket

@@ -94,8 +94,20 @@ def vector_potential(x, y, z, b, niterex_max=10000, ncycles_max=1024, ex_tol=1e-
         ioptc[lib.get_iopt_prec()] = int(mixed_precision)    # True/1: where level 1 is large; 2: wherever the fp32 kernels apply
 
     apot = np.zeros(b.size, dtype=np.float64)
-    bflat = b.flatten()
+    if hasattr(lib, "ndsm_hip_init") and b.ndim == 4 and b.shape[0] == 3 and min(b.shape[1:]) >= 2:
+        # libndsm_hip reads nothing of B but its normal component on the six faces (as the reference does,
+        # ndsm_vector_potential.f90:283-299) and overwrites all of it: hand over a fresh buffer that carries
+        # just those faces instead of the reference's 3-array copy b.flatten() (ndsm.py:177; 3 GiB at 512^3)
+        bflat = np.empty(b.size, dtype=b.dtype)
+        bv = bflat.reshape(b.shape)
+        bv[0][:, :, 0], bv[0][:, :, -1] = b[0][:, :, 0], b[0][:, :, -1]
+        bv[1][:, 0, :], bv[1][:, -1, :] = b[1][:, 0, :], b[1][:, -1, :]
+        bv[2][0], bv[2][-1] = b[2][0], b[2][-1]
+    else:
+        bflat = b.flatten()
     ierr = lib.ndsm_vector_solve(ctypes.c_size_t(b.size), nshape, ioptc, ropt, x, y, z, apot, bflat)
+    if ierr >= 9001:
+        bflat = b.flatten()          # device / runtime failure: B comes back as it went in
     return ierr, apot.reshape(nshape[::-1]), bflat.reshape(nshape[::-1])
 
 
