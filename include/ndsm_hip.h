@@ -50,7 +50,9 @@ extern "C" {
  *   B        in: field whose NORMAL component on the six faces is the
  *            boundary data; out: curl A, (nx,ny,nz,3)
  * returns ioptc[IOPT_IERR]: 0 ok, 1 not converged / bad mesh (see DESIGN.md
- * quirk Q3' for which solve's flag the reference actually returns). */
+ * quirk Q3' for which solve's flag the reference actually returns).
+ * After a device / runtime failure (>= 9001) the contents of A and B are unspecified (a worker thread has
+ * begun to touch and fill them behind the solves). */
 int ndsm_vector_solve(size_t nsize, const int *nshape4, int *ioptc, double *ropt, const double *x,
                       const double *y, const double *z, double *A, double *B);
 
