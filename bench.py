@@ -100,6 +100,47 @@ def cpu_baseline(n=512, seconds_budget=8.0):
     return out
 
 
+def live_traffic(n, zero_rhs, kernel_sub, timeout_s=75):
+    """HBM bytes of one launch of the dominant kernel MEASURED IN THIS RUN: two child runs of rocprofv3 (kernel
+    trace + ONE counter each - FETCH_SIZE, WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes) over
+    scripts/run_sweeps.py; FETCH_SIZE doubled (gfx950 tallies the 128-B requests of 16-B/lane streams at 64 B).
+    Returns (bytes per launch, source text) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ):
+        return None, "this run is itself being profiled"
+    tmp = tempfile.mkdtemp(prefix="ndsm_bench_pmc_")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--",
+                   sys.executable, os.path.join(ROOT, "scripts", "run_sweeps.py"), str(n), "7"] + (["zero"] if zero_rhs else [])
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s,
+                               cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"))
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
+            got = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                   if row["Counter_Name"] == ctr and kernel_sub in row["Kernel_Name"].replace(" ", "")]
+            if not got:
+                return None, f"kernel not found in the {ctr} pass"
+            vals[ctr] = sum(got) / len(got)
+    except Exception as exc:  # noqa: BLE001
+        return None, f"{type(exc).__name__}: {exc}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0          # the counters are in KiB
+    return total, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child "
+                   "passes over scripts/run_sweeps.py), FETCH_SIZE x 2 (gfx950), per-launch average")
+
+
 def end_to_end_fresh(n):
     """the same two calls in a FRESH process (what a user's first call costs: HIP runtime bring-up and
     code-object load, hierarchy set-up, first touch of the result pages), as a child process"""
@@ -246,6 +287,8 @@ def main():
     ap.add_argument("--ms", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-solve / ndsm_vector_solve timings")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="take roofline.traffic from profiles/traffic_latest.json instead of two rocprofv3 --pmc child runs")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: everything else this process and the native libraries under it write to
@@ -464,7 +507,17 @@ def main():
         except Exception:  # noqa: BLE001
             traffic = traffic_gen = None
 
-    def roofline(ms_sweep, bytes_per_lup, kernel, tr):
+    # ... unless the counters can be read right now (rank 0, one GPU, the 512^3 workload): then `traffic` IS measured
+    # in this run, by two short child runs under rocprofv3
+    tsrc_gen = tsrc
+    if world == 1 and args.n == 512 and not args.no_live_traffic:
+        t_live, src = live_traffic(args.n, True, "rbgs3_fused_k<double,2,136,30,1024,4,true,0,true,false>")
+        if t_live:
+            traffic, tsrc = t_live, src
+        else:
+            tsrc = (tsrc or "") + f" [live measurement skipped: {src}]"
+
+    def roofline(ms_sweep, bytes_per_lup, kernel, tr, src=None):
         launch_s = 2 * ms_sweep * 1e-3
         alg = 2 * bytes_per_lup * npts / world                    # per launch and GPU: two sweeps
         r = {"bound": "hbm", "achieved": alg / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -473,7 +526,7 @@ def main():
              "algorithmic_bytes_per_launch": alg, "avg_launch_ms": launch_s * 1e3,
              "frac_algorithmic": alg / launch_s / 1e9 / HBM_PEAK_GBS,
              "frac_hbm": (tr / launch_s / 1e9 / HBM_PEAK_GBS) if tr else None,
-             "traffic_source": tsrc if tr else None,
+             "traffic_source": (src if src is not None else tsrc) if tr else None,
              "note": "frac = frac_algorithmic = SURVEY 8d algorithmic bytes (bytes_per_lup x 2 sweeps x points) / launch "
                      "time / 8 TB/s: one launch performs TWO sweeps on one pass over HBM (temporal blocking), so it "
                      "can exceed what the memory system moves; frac_hbm = HBM bytes the launch really moved "
@@ -523,7 +576,8 @@ def main():
     }
     if gen_ms:
         out["roofline_general_rhs"] = roofline(gen_ms, BYTES_PER_LUP,
-                                               "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, false, 0, true, false>", traffic_gen)
+                                               "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, false, 0, true, false>", traffic_gen,
+                                               tsrc_gen)
     if solve_info:
         out["solve"] = solve_info
     if slab_check is not None:
