@@ -104,6 +104,7 @@ int ndsmk_host_free(void *p);
 int ndsmk_mem_info(size_t *free_bytes, size_t *total_bytes);
 int ndsmk_h2d_async(void *dst, const void *h_pinned_src, size_t bytes);
 void ndsmk_at_reset(void (*fn)(void));                      /* fn runs at the next shutdown / re-target */
+void ndsmk_on_low_memory(void (*fn)(void));                 /* fn runs when a device allocation fails, before one retry */
 
 /* ---- kernels ------------------------------------------------------- */
 /* nsweeps full red-black Gauss-Seidel sweeps (ndsm_optimized.f90:40-191 in

@@ -156,6 +156,7 @@ void bg_stop() {
   g_bg.running = false;
 }
 
+std::vector<void (*)()> g_lowmem_hooks;   // called when a device allocation fails, before it is retried once
 int g_epoch = 0;                       // see common.hpp
 std::vector<void (*)()> g_reset_hooks;
 
@@ -271,8 +272,23 @@ int ndsmk_alloc(void **p, size_t bytes) {
   NDSM_REQUIRE_READY();
   *p = nullptr;
   if (bytes == 0) bytes = 8;
-  NDSM_HIP(hipMalloc(p, bytes));
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory && !g_lowmem_hooks.empty()) {
+    // memory the library keeps for the caller's convenience (the cached vector-potential context) goes first
+    (void)hipGetLastError();
+    for (auto fn : g_lowmem_hooks) fn();
+    e = hipMalloc(p, bytes);
+  }
+  NDSM_HIP(e);
   return 0;
+}
+
+// fn: release whatever is held only as a cache (must be safe to call at any allocation; a holder that is in
+// the middle of using its memory does nothing)
+void ndsmk_on_low_memory(void (*fn)(void)) {
+  for (auto f : g_lowmem_hooks)
+    if (f == fn) return;
+  g_lowmem_hooks.push_back(fn);
 }
 
 int ndsmk_free(void *p) {

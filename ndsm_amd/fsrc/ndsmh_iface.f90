@@ -353,6 +353,10 @@ module ndsmh_iface
       integer(c_size_t), value :: bytes
       integer(c_int) :: rc
     end function
+    subroutine ndsmk_on_low_memory(fn) bind(c, name="ndsmk_on_low_memory")
+      import :: c_funptr
+      type(c_funptr), value :: fn
+    end subroutine
     subroutine ndsmk_at_reset(fn) bind(c, name="ndsmk_at_reset")
       import :: c_funptr
       type(c_funptr), value :: fn

@@ -86,6 +86,7 @@ module ndsmh_vecpot
   end type
 
   type(vecpot_ctx), save, target :: cache
+  logical, save :: cache_busy = .false.     ! ndsm_vector_solve is running on the cached context
 
 contains
 
@@ -352,6 +353,12 @@ contains
     call vecpot_ctx_destroy(cache)
   end subroutine
 
+  ! a device allocation somewhere in the library has failed: the cached context (13 GiB at 512^3) is only a
+  ! convenience - give it back, unless ndsm_vector_solve is using it right now
+  subroutine vecpot_cache_evict() bind(c)
+    if (.not. cache_busy) call vecpot_ctx_destroy(cache)
+  end subroutine
+
   function vecpot_solve(n3, iopt, ropt, qx, qy, qz, A, B) result(rc)
     integer(c_int32_t), intent(in) :: n3(3)
     integer(ik), intent(inout) :: iopt(0:OPT_LEN - 1)
@@ -366,17 +373,21 @@ contains
       rc = 0
       return
     end if
+    cache_busy = .true.      ! (an allocation failure below must not evict the context that is being built / used)
     call get_environment_variable("NDSM_HIP_NO_CACHE", status=st)      ! A/B testing: rebuild everything per call
     if (st == 0) call vecpot_ctx_destroy(cache)
     if (.not. vecpot_ctx_matches(cache, n3, qx, qy, qz, int(iopt(IOPT_NGRIDS)))) then
       rc = vecpot_ctx_create(cache, n3, qx, qy, qz, int(iopt(IOPT_NGRIDS)))
       if (rc /= 0) then
         call vecpot_ctx_destroy(cache)
+        cache_busy = .false.
         return
       end if
       call ndsmk_at_reset(c_funloc(vecpot_cache_drop))
+      call ndsmk_on_low_memory(c_funloc(vecpot_cache_evict))
     end if
     rc = vecpot_run(cache, iopt, ropt, c_loc(A), c_loc(B), .false.)
+    cache_busy = .false.
     if (rc /= 0 .or. st == 0) call vecpot_ctx_destroy(cache)    ! after an error nothing is assumed about the device state
   end function
 

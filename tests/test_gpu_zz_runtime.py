@@ -2,6 +2,7 @@
 parity tests): bring-up of the REAL RCCL library on one rank, and shutdown / re-initialisation of the
 device runtime with everything the library caches on the device."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -94,3 +95,47 @@ def test_shutdown_and_reinit(hip):
     assert np.array_equal(A1, A2) and np.array_equal(B1, B2)
     h3, a3 = run()
     assert h1 == h3 and np.array_equal(a1, a3)
+
+
+def test_cached_context_is_evicted_when_memory_runs_out(hip):
+    """ndsm_vector_solve keeps its hierarchies and device arrays for the next call on the same mesh; an
+    allocation that does not fit next to them must get that memory back instead of failing: a 320^3 call
+    (3.4 GiB cached), then device allocations that leave less than that free, then a solver that needs it"""
+    import ndsm_amd
+    L = hip.load_library()
+    L.ndsm_hip_device_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+    L.ndsm_hip_device_free.argtypes = [ctypes.c_void_p]
+    hipdll = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so", mode=os.RTLD_NOW | os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hipdll.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    n = 320
+    x, y, z, _A1, b1 = analytic_case(n)
+    f0 = free_bytes()
+    ierr, A, B = ndsm_amd.vector_potential(x, y, z, b1)
+    held = f0 - free_bytes()
+    assert ierr == 0 and held > 2 * 2**30, held                     # the cache is alive
+    # fill the device until less than the cached amount is left
+    blocks = []
+    try:
+        chunk = 8 * 2**30
+        while free_bytes() > chunk + 2**30:
+            p = ctypes.c_void_p()
+            assert L.ndsm_hip_device_alloc(chunk, ctypes.byref(p)) == 0
+            blocks.append(p)
+        left = free_bytes()
+        # a solver whose level-1 arrays alone need more than what is left, but less than left + cache
+        need_pts = int((left + held // 2) / (5.5 * 8))
+        m = int(round(need_pts ** (1.0 / 3.0))) & ~1
+        mesh = uniform_mesh([m, m, m])
+        S = hip.MGSolver([m, m, m], mesh, "NDDNDD")                     # succeeds only if the cache was given back
+        S.close()
+        assert f0 - free_bytes() - len(blocks) * chunk < held // 4      # ... and it was
+    finally:
+        for p in blocks:
+            L.ndsm_hip_device_free(p)
+    ierr2, A2, B2 = ndsm_amd.vector_potential(x, y, z, b1)            # rebuilt on demand, same bits
+    assert np.array_equal(A, A2) and np.array_equal(B, B2)
