@@ -446,7 +446,7 @@ def main():
 
     # ---- dominant kernel: the level-1 smoother launches under HIP events on the library stream ----
     nsw = 20
-    vc_only_ms = gen_ms = rs_ms = sweeps_per_cycle = None
+    vc_only_ms = gen_ms = rs_ms = sweeps_per_cycle = one_gpu_ms = None
     solve_info = None
     if world == 1:
         S.vcycle(2)
@@ -487,6 +487,25 @@ def main():
         lap_ms = float(t[0])
         bpl = BYTES_PER_LUP
         kname = "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, false, 0, *> on z-slab windows, halo exchange included"
+        # the SAME workload on one GPU (rank 0's, the others wait): the driver's N = 1 line is the 512^3
+        # Laplace problem, so the strong-scaling ratio of this configuration needs its own one-GPU time
+        if rank == 0 and not args.no_e2e:
+            try:
+                S1 = _lib.MGSolver(n3, mesh, "NDDNDD", ms=ms, lib=L)
+                _m, full, _a = slab_window_problem(n3, {"k0": 0, "nloc": n3[2]})
+                S1.upload(1, _lib.BUF_RHS, full)
+                del full
+                S1.solve(vc_tol=0.0, nmax=2)
+                S1.sync()
+                t0 = time.perf_counter()
+                S1.solve(vc_tol=0.0, nmax=args.steps)
+                S1.sync()
+                one_gpu_ms = (time.perf_counter() - t0) / args.steps * 1e3
+                S1.close()
+                del S1
+            except Exception as exc:  # noqa: BLE001
+                one_gpu_ms = None
+                print(f"bench: one-GPU time of the slab workload not taken: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
     S.close()
     del S
 
@@ -582,6 +601,10 @@ def main():
         out["solve"] = solve_info
     if slab_check is not None:
         out["slab_check"] = slab_check
+    if one_gpu_ms:
+        out["same_workload_on_one_gpu"] = {"ms_per_step": one_gpu_ms, "speedup": one_gpu_ms / ms_per_step,
+                                           "what": "the identical 1024x1024x512 problem and loop on rank 0's GPU alone, "
+                                                   "timed after the N-GPU region (strong-scaling reference)"}
     if world == 1 and not args.no_e2e:
         try:
             out["end_to_end"] = end_to_end(L, args.n)

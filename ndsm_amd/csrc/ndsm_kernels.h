@@ -146,6 +146,16 @@ int ndsmk_diff_metrics(const double *a, double *b, int64_t n, int copy, double *
 int ndsmk_solve_exact(const ndsmk_grid *g, double *u, const double *rhs, double *scratch,
                       double ex_tol, int use_max, int nmax, int64_t *d_info);
 
+/* The bottom of a V-cycle as ONE single-workgroup launch (tail.hip): levels g[0..nlev-1] (g[nlev-1] the
+ * coarsest grid, x[q] the transfer g[q] -> g[q+1], u[q] / rhs[q] their DEVICE arrays), all resident in LDS:
+ * ms sweeps + residual + restriction down, solve_exact + ms sweeps, interpolation + 2 ms sweeps up.
+ * ndsmk_tail_applies: 1 if these levels are covered (3-D, whole levels, <= 6144 points, <= 4 levels).
+ * Bit-identical to the level-by-level kernels.  ndsmk_debug_tail(0 / 1): tests switch it off / on. */
+int ndsmk_tail_applies(int nlev, const ndsmk_grid *g, const ndsmk_xfer *x);
+int ndsmk_tail_cycle(int nlev, const ndsmk_grid *g, const ndsmk_xfer *x, double *const *u, double *const *rhs, int ms,
+                     double ex_tol, int use_max, int nmax, int64_t *d_info);
+int ndsmk_debug_tail(int on);
+
 /* A += flux-balance fields, B = curl A (+ linear field when curl_first), all on
  * device arrays (nx,ny,nz,3); x,y,z are DEVICE mesh vectors, h_* host scalars
  * (ndsm_vector_potential.f90:453-477, :759-872, :880-950) */

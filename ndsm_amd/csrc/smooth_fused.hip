@@ -997,7 +997,8 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   // (*sweeps_done = 0) and the caller interpolates with the stand-alone kernel first.
   if (prol) {
     if constexpr (std::is_same<T, double>::value) {
-      if (!rhs && two && !(met && max_sweeps == 2) && cfg[0] == 0) {
+      static const bool prol_rhs = std::getenv("NDSM_PROL_RHS") != nullptr;
+      if ((!rhs || prol_rhs) && two && !(met && max_sweeps == 2) && cfg[0] == 0) {
         rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 3, false, ODD>(g, u, uout, rhs, tgt, nullptr, nullptr, prol));
         if (rc) return rc;
         *sweeps_done = 2;

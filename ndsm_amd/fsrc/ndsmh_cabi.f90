@@ -948,6 +948,14 @@ contains
     rc = ndsmk_debug_tile_max(max_points)
   end function
 
+  ! development hook: 0 = the levels of the V-cycle's tail run kernel by kernel even where the single-launch
+  ! form (tail.hip) covers them, 1 = default
+  function ndsm_hip_debug_tail(on) bind(c, name="ndsm_hip_debug_tail") result(rc)
+    integer(c_int), value :: on
+    integer(c_int) :: rc
+    rc = ndsmk_debug_tail(on)
+  end function
+
   function ndsm_hip_world_vcycle(handle, ncycles) bind(c, name="ndsm_hip_world_vcycle") result(rc)
     type(c_ptr), value :: handle
     integer(c_int), value :: ncycles

@@ -278,6 +278,34 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_tail_applies(nlev, g, x) bind(c, name="ndsmk_tail_applies") result(ok)
+      import :: ndsmk_grid, ndsmk_xfer, c_int
+      integer(c_int), value :: nlev
+      type(ndsmk_grid), intent(in) :: g(*)
+      type(ndsmk_xfer), intent(in) :: x(*)
+      integer(c_int) :: ok
+    end function
+
+    function ndsmk_tail_cycle(nlev, g, x, u, rhs, ms, ex_tol, use_max, nmax, d_info) &
+        bind(c, name="ndsmk_tail_cycle") result(rc)
+      import :: ndsmk_grid, ndsmk_xfer, c_ptr, c_int, c_double
+      integer(c_int), value :: nlev
+      type(ndsmk_grid), intent(in) :: g(*)
+      type(ndsmk_xfer), intent(in) :: x(*)
+      type(c_ptr), intent(in) :: u(*), rhs(*)
+      integer(c_int), value :: ms
+      real(c_double), value :: ex_tol
+      integer(c_int), value :: use_max, nmax
+      type(c_ptr), value :: d_info
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_debug_tail(on) bind(c, name="ndsmk_debug_tail") result(rc)
+      import :: c_int
+      integer(c_int), value :: on
+      integer(c_int) :: rc
+    end function
+
     function ndsmk_balance_curl(A, B, n3, x, y, z, phi6, span3, dq3, curl_first) &
         bind(c, name="ndsmk_balance_curl") result(rc)
       import :: c_ptr, c_int, c_int32_t, c_double

@@ -551,10 +551,13 @@ contains
     type(mg_solver), intent(inout) :: s
     integer, intent(in) :: ltop
     integer(c_int) :: rc
-    integer :: l
+    integer :: l, lt
+
+    ! levels lt .. ngrids run as ONE launch with all of them in LDS (tail.hip); lt = ngrids + 1: none do
+    lt = tail_first(s, ltop)
 
     ! descend: pre-smooth, residual, restrict (fine_to_coarse, :482-560)
-    do l = ltop, s%ngrids - 1
+    do l = ltop, min(lt, s%ngrids) - 1
       if (s%xf(l)%fused_rr .and. .not. (s%slab .and. l == 1) .and. s%allow_fused_rr) then
         rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
         rc = ndsmk_residual_restrict(s%lev(l)%g, s%xf(l)%x, s%dl(l)%u, s%dl(l)%rhs, s%dl(l + 1)%rhs, s%dl(l + 1)%u)
@@ -566,7 +569,11 @@ contains
     end do
 
     ! coarsest grid: iterate the smoother to ex_tol (solve_exact, :728-800)
-    rc = mg_op(s, MG_OP_EXACT, s%ngrids, 1); if (rc /= 0) return
+    if (lt <= s%ngrids) then
+      rc = tail_cycle(s, lt); if (rc /= 0) return
+    else
+      rc = mg_op(s, MG_OP_EXACT, s%ngrids, 1); if (rc /= 0) return
+    end if
 
     ! ascend: smooth the coarse problem, interpolate + correct, post-smooth
     ! (coarse_to_fine, :593-684)
@@ -575,8 +582,10 @@ contains
     ! array.  They are issued as ONE relax call here (five two-sweep passes instead of 2+2+1 twice on the
     ! streamed levels, one launch instead of two on the single-workgroup levels) - the same sweeps in the
     ! same order.
-    rc = mg_op(s, MG_OP_RELAX, s%ngrids, s%ms); if (rc /= 0) return
-    do l = s%ngrids, ltop + 1, -1
+    if (lt > s%ngrids) then
+      rc = mg_op(s, MG_OP_RELAX, s%ngrids, s%ms); if (rc /= 0) return
+    end if
+    do l = min(lt, s%ngrids), ltop + 1, -1
       if (l - 1 == 1 .and. s%track) then      ! interpolate + correct + post-smooth as one call
         rc = relax_tracked(s, s%ms, .false., .true., prolong=.true.); if (rc /= 0) return
       else
@@ -589,6 +598,51 @@ contains
       end if
     end do
     rc = 0
+  end function
+
+  ! First level of the V-cycle's tail: the smallest lt > ltop (lt >= 2) from which every level down to the
+  ! coarsest grid fits the single-launch kernel of tail.hip; ngrids + 1 if there is none.  (A few dozen
+  ! integer comparisons per V-cycle: not cached, so that boundary letters and the test switch can change.)
+  function tail_first(s, ltop) result(lt)
+    type(mg_solver), intent(in) :: s
+    integer, intent(in) :: ltop
+    integer :: lt
+    integer :: l, q, nlev
+    type(ndsmk_grid) :: gg(4)
+    type(ndsmk_xfer) :: xx(3)
+    lt = s%ngrids + 1
+    if (s%ndim /= 3 .or. .not. s%has_coarse) return
+    do l = max(2, ltop + 1), s%ngrids - 1           ! (the kernel needs two levels)
+      nlev = s%ngrids - l + 1
+      if (nlev > 4) cycle
+      do q = 1, nlev
+        gg(q) = s%lev(l + q - 1)%g
+        if (q < nlev) xx(q) = s%xf(l + q - 1)%x
+      end do
+      if (ndsmk_tail_applies(int(nlev, c_int), gg, xx) /= 0) then
+        lt = l
+        exit
+      end if
+    end do
+  end function
+
+  function tail_cycle(s, lt) result(rc)
+    type(mg_solver), intent(inout) :: s
+    integer, intent(in) :: lt
+    integer(c_int) :: rc
+    integer :: q, nlev
+    type(ndsmk_grid) :: gg(4)
+    type(ndsmk_xfer) :: xx(3)
+    type(c_ptr) :: uu(4), rr(4)
+    nlev = s%ngrids - lt + 1
+    do q = 1, nlev
+      gg(q) = s%lev(lt + q - 1)%g
+      if (q < nlev) xx(q) = s%xf(lt + q - 1)%x
+      uu(q) = s%dl(lt + q - 1)%u
+      rr(q) = s%dl(lt + q - 1)%rhs
+    end do
+    rc = ndsmk_tail_cycle(int(nlev, c_int), gg, xx, uu, rr, int(s%ms, c_int), s%ex_tol, &
+                          merge(1_c_int, 0_c_int, s%use_max), int(s%nmax_exact, c_int), s%info)
   end function
 
   ! z-slab level 1, pieces of a pass whose halo exchange overlaps its interior: one fused pass

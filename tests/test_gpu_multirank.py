@@ -185,3 +185,5 @@ def test_bench_two_ranks_rehearsal(hip):
     assert out["slab_check"].startswith("bit-identical") and "MISMATCH" not in out["slab_check"], out["slab_check"]
     assert out["slab_mode"] is True and out["rccl_ranks"] == 2
     assert "fake_rccl" in out["rocm_stack"]["rccl"]
+    one = out["same_workload_on_one_gpu"]               # both ranks share this GPU: the split cannot be faster
+    assert one["ms_per_step"] > 0 and 0.2 < one["speedup"] < 1.3, one

@@ -1292,6 +1292,57 @@ def test_tile_smoother_bitwise(hip, port, ns):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ns", ([64, 64, 64], [33, 22, 27], [40, 24, 32], [100, 37, 51], [128, 128, 128], [144, 144, 72],
+                                [22, 22, 22], [40, 136, 72]), ids=_tag)
+def test_tail_cycle_bitwise(hip, ns):
+    """the bottom of the V-cycle as ONE single-workgroup launch (tail.hip: every level of <= 6144 points
+    resident in LDS - sweeps, residual, restriction, coarsest-grid solve, interpolation) against the same
+    levels run kernel by kernel (switched through the development hook): V-cycles from random data, every
+    level's u and rhs afterwards, the coarsest-grid sweep counters, the du history of a solve - bit for bit;
+    max and mean form of the coarsest grid's stop test, ms = 1 ... 5, an unconverged coarsest solve"""
+    L = hip.load_library()
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u, rhs = rand_field(shp, 7), rand_field(shp, 8)
+    ran = 0
+
+    def run(bcs, ms, du_max, nmax_exact):
+        S = hip.MGSolver(ns, mesh, bcs, ms=ms, du_max=du_max, nmax_exact=nmax_exact)
+        S.upload(1, hip.BUF_U, u)
+        S.upload(1, hip.BUF_RHS, rhs)
+        S.vcycle(2)
+        lev = [(S.download(l, hip.BUF_U), S.download(l, hip.BUF_RHS)) for l in range(1, S.ngrids + 1)]
+        info = S.info()
+        ie, du, nc, h = S.solve(vc_tol=1e-9, nmax=6, hist_len=8)
+        out = S.download(1, hip.BUF_U)
+        sizes = [int(np.prod(sh)) for sh in S.shapes]
+        S.close()
+        return lev, info, (ie, du, nc, list(h)), out, sizes
+
+    try:
+        for bcs, ms, du_max, nmax_exact in (("NDDNDD", 5, True, 10000), ("DNDDND", 5, False, 10000), ("DDNDDN", 3, True, 10000),
+                                            ("NNNNND", 1, False, 10000), ("DDDDDD", 2, True, 3), ("NDNDND", 4, True, 10000)):
+            L.ndsm_hip_debug_tail(0)
+            want = run(bcs, ms, du_max, nmax_exact)
+            L.ndsm_hip_debug_tail(1)
+            got = run(bcs, ms, du_max, nmax_exact)
+            sizes = want[4]
+            if len(sizes) >= 3 and sizes[-2] <= 6144:
+                ran += 1                      # (at least the two coarsest levels qualify)
+            for l, (a, b) in enumerate(zip(want[0], got[0]), start=1):
+                assert np.array_equal(a[0], b[0]), (bcs, "u", l)
+                assert np.array_equal(a[1], b[1]), (bcs, "rhs", l)
+            assert want[1] == got[1], (bcs, want[1], got[1])
+            assert want[2] == got[2], (bcs, want[2], got[2])
+            assert np.array_equal(want[3], got[3]), bcs
+            if nmax_exact == 3:
+                assert want[1][1] > 0           # the coarsest solves did run out of sweeps
+        assert ran > 0
+    finally:
+        L.ndsm_hip_debug_tail(1)
+
+
+@pytest.mark.gpu
 def test_baseline_config4_full_grid_mixed_component(hip):
     """BASELINE config[4]'s grid at FULL size - 2048 x 2048 x 1024 = 2^32 points, 32 GiB per fp64 array - and
     in its precision mode (fp32 smoother / fp64 residual): two solve-loop cycles of ONE component (Ay's
