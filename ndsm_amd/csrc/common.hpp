@@ -12,6 +12,7 @@ namespace ndsm {
 
 // one library stream; every kernel, copy and RCCL call is ordered on it
 hipStream_t stream();
+int lane();   // the selected lane (ndsmk_select_lane), -1: none
 bool ready();
 int cu_count();
 // Device-bound process state.  epoch() changes every time the runtime comes up on a device

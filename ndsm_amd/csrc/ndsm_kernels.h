@@ -138,6 +138,9 @@ int ndsmk_prolong_add(const ndsmk_xfer *x, const double *u_c, double *u_f);
 /* blocking: out[0] = max|a-b|, out[1] = sum|a-b| ; then b <- a if copy != 0
  * (update_u, ndsm_multigrid_core.f90:1077-1122 ; du_metrics :808-853) */
 int ndsmk_diff_metrics(const double *a, double *b, int64_t n, int copy, double *h_out2);
+/* its two halves: enqueue on the selected stream / lane; wait for that stream and read the pair */
+int ndsmk_diff_metrics_begin(const double *a, double *b, int64_t n, int copy);
+int ndsmk_diff_metrics_end(double *h_out2);
 /* coarsest-grid "exact" solve (ndsm_multigrid_core.f90:728-800): repeat
  * {test du <= ex_tol first; relax; du = max|.| or mean|.| of the change} at most
  * nmax times.  d_info (DEVICE, 2 x int64) accumulates [0] sweeps done and
@@ -199,6 +202,10 @@ int ndsmk_fused_metric_ok(const ndsmk_grid *g);
 int ndsmk_fused_prolong_ok(const ndsmk_grid *g, const double *rhs, int nsweeps);
 /* two streams: 1 = later copies / RCCL calls go to the communication stream, 0 = main stream again;
  * fence(from, to): work enqueued on `from` so far precedes work enqueued on `to` from now on */
+#define NDSMK_LANES 6
+int ndsmk_select_lane(int lane);           /* -1: main stream */
+int ndsmk_lane_fence(int lane, int to_main);
+int ndsmk_lane_sync(int lane);
 int ndsmk_select_stream(int which);
 int ndsmk_stream_fence(int from, int to);
 

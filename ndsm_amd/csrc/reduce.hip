@@ -19,12 +19,15 @@ struct Scratch {
   double *d_part = nullptr;  // [2 * kRedMaxBlocks + 2]
   double *h_pin = nullptr;   // [4] pinned
 };
-Scratch g_s;
+Scratch g_sl[NDSMK_LANES + 1];   // [0] the main stream's, [1 + l] lane l's (ndsmk_select_lane): lanes run concurrently
+#define g_s (g_sl[ndsm::lane() + 1])
 
 void scratch_release() {
-  if (g_s.d_part) (void)hipFree(g_s.d_part);
-  if (g_s.h_pin) (void)hipHostFree(g_s.h_pin);
-  g_s = Scratch();
+  for (auto &s : g_sl) {
+    if (s.d_part) (void)hipFree(s.d_part);
+    if (s.h_pin) (void)hipHostFree(s.h_pin);
+    s = Scratch();
+  }
 }
 int ensure_scratch() {
   if (g_s.d_part) return 0;
@@ -170,7 +173,9 @@ int launch_mean_shift(double *u, int64_t n) {
 
 }  // namespace ndsm
 
-extern "C" int ndsmk_diff_metrics(const double *a, double *b, int64_t n, int copy, double *h_out2) {
+// the two halves of ndsmk_diff_metrics: enqueue (on the selected stream / lane, result on its way to that
+// lane's pinned pair) and collect (waits for that stream).  Between the two the caller may enqueue on OTHER lanes.
+extern "C" int ndsmk_diff_metrics_begin(const double *a, double *b, int64_t n, int copy) {
   NDSM_REQUIRE_READY();
   NDSM_CHECK_ARG(n > 0);
   if (int rc = ensure_scratch()) return rc;
@@ -182,10 +187,19 @@ extern "C" int ndsmk_diff_metrics(const double *a, double *b, int64_t n, int cop
   hipLaunchKernelGGL(diff_stage2, dim3(1), dim3(kRedBlock), 0, s, g_s.d_part, nb, out);
   NDSM_LAUNCH_CHECK();
   NDSM_HIP(hipMemcpyAsync(g_s.h_pin, out, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-  NDSM_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+extern "C" int ndsmk_diff_metrics_end(double *h_out2) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(g_s.h_pin != nullptr);
+  NDSM_HIP(hipStreamSynchronize(ndsm::stream()));
   h_out2[0] = g_s.h_pin[0];
   h_out2[1] = g_s.h_pin[1];
   return 0;
+}
+extern "C" int ndsmk_diff_metrics(const double *a, double *b, int64_t n, int copy, double *h_out2) {
+  if (int rc = ndsmk_diff_metrics_begin(a, b, n, copy)) return rc;
+  return ndsmk_diff_metrics_end(h_out2);
 }
 
 // Coarsest-grid solve.  Normal case: the single-workgroup LDS kernel in

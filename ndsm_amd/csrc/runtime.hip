@@ -23,6 +23,12 @@ struct Runtime {
   hipStream_t comm = nullptr;   // halo traffic that overlaps kernels of the main stream (z-slab worlds)
   bool on_comm = false;         // enqueue copies / RCCL calls on `comm` for now (ndsmk_select_stream)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evx = nullptr;
+  // lanes: a few more streams for INDEPENDENT small solves that are pure dispatch latency one after the
+  // other (the six 2-D face problems of the vector potential); while a lane is selected everything the
+  // library enqueues goes to that lane's stream (ndsmk_select_lane), created on first use
+  hipStream_t lane[NDSMK_LANES] = {};
+  hipEvent_t lane_ev[NDSMK_LANES] = {};
+  int cur_lane = -1;
   char err[512] = "no error";
 };
 
@@ -166,11 +172,20 @@ void tear_down() {
   bg_stop();
   (void)hipStreamSynchronize(g_rt.stream);
   (void)hipStreamSynchronize(g_rt.comm);
+  for (int l = 0; l < NDSMK_LANES; ++l)
+    if (g_rt.lane[l]) (void)hipStreamSynchronize(g_rt.lane[l]);
   std::vector<void (*)()> hooks;
   hooks.swap(g_reset_hooks);
   for (auto fn : hooks) fn();
   (void)hipStreamDestroy(g_rt.stream);
   (void)hipStreamDestroy(g_rt.comm);
+  for (int l = 0; l < NDSMK_LANES; ++l) {
+    if (g_rt.lane[l]) (void)hipStreamDestroy(g_rt.lane[l]);
+    if (g_rt.lane_ev[l]) (void)hipEventDestroy(g_rt.lane_ev[l]);
+    g_rt.lane[l] = nullptr;
+    g_rt.lane_ev[l] = nullptr;
+  }
+  g_rt.cur_lane = -1;
   (void)hipEventDestroy(g_rt.evx);
   (void)hipEventDestroy(g_rt.ev0);
   (void)hipEventDestroy(g_rt.ev1);
@@ -181,7 +196,11 @@ void tear_down() {
 
 namespace ndsm {
 
-hipStream_t stream() { return g_rt.on_comm ? g_rt.comm : g_rt.stream; }
+hipStream_t stream() {
+  if (g_rt.on_comm) return g_rt.comm;
+  return g_rt.cur_lane >= 0 ? g_rt.lane[g_rt.cur_lane] : g_rt.stream;
+}
+int lane() { return g_rt.cur_lane; }
 bool ready() { return g_rt.up; }
 int cu_count() { return g_rt.ncu > 0 ? g_rt.ncu : 256; }
 int epoch() { return g_epoch; }
@@ -296,6 +315,8 @@ int ndsmk_free(void *p) {
   NDSM_REQUIRE_READY();
   NDSM_HIP(hipStreamSynchronize(g_rt.comm));   // halo copies / RCCL calls may still read it
   NDSM_HIP(hipStreamSynchronize(g_rt.stream));
+  for (int l = 0; l < NDSMK_LANES; ++l)
+    if (g_rt.lane[l]) NDSM_HIP(hipStreamSynchronize(g_rt.lane[l]));
   NDSM_HIP(hipFree(p));
   return 0;
 }
@@ -322,7 +343,7 @@ int ndsmk_d2d(void *dst, const void *src, size_t bytes) {
 
 int ndsmk_fill0(void *p, size_t bytes) {
   NDSM_REQUIRE_READY();
-  NDSM_HIP(hipMemsetAsync(p, 0, bytes, g_rt.stream));
+  NDSM_HIP(hipMemsetAsync(p, 0, bytes, g_rt.cur_lane >= 0 ? g_rt.lane[g_rt.cur_lane] : g_rt.stream));
   return 0;
 }
 
@@ -330,6 +351,42 @@ int ndsmk_sync(void) {
   NDSM_REQUIRE_READY();
   NDSM_HIP(hipStreamSynchronize(g_rt.comm));
   NDSM_HIP(hipStreamSynchronize(g_rt.stream));
+  for (int l = 0; l < NDSMK_LANES; ++l)
+    if (g_rt.lane[l]) NDSM_HIP(hipStreamSynchronize(g_rt.lane[l]));
+  return 0;
+}
+
+// Lanes.  ndsmk_select_lane(l), 0 <= l < NDSMK_LANES: kernels, device copies and fills issued from now on go
+// to lane l's stream (and the reductions use lane l's scratch); -1: back to the main stream.
+// ndsmk_lane_fence(l, 0): lane l waits for everything enqueued on the main stream so far;
+// ndsmk_lane_fence(l, 1): the main stream waits for everything enqueued on lane l so far.
+// ndsmk_lane_sync(l): the host waits for lane l.
+int ndsmk_select_lane(int lane) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(lane >= -1 && lane < NDSMK_LANES);
+  if (lane >= 0 && !g_rt.lane[lane]) {
+    NDSM_HIP(hipStreamCreateWithFlags(&g_rt.lane[lane], hipStreamNonBlocking));
+    NDSM_HIP(hipEventCreateWithFlags(&g_rt.lane_ev[lane], hipEventDisableTiming));
+  }
+  g_rt.cur_lane = lane;
+  return 0;
+}
+int ndsmk_lane_fence(int lane, int to_main) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(lane >= 0 && lane < NDSMK_LANES && g_rt.lane[lane]);
+  if (to_main) {
+    NDSM_HIP(hipEventRecord(g_rt.lane_ev[lane], g_rt.lane[lane]));
+    NDSM_HIP(hipStreamWaitEvent(g_rt.stream, g_rt.lane_ev[lane], 0));
+  } else {
+    NDSM_HIP(hipEventRecord(g_rt.lane_ev[lane], g_rt.stream));
+    NDSM_HIP(hipStreamWaitEvent(g_rt.lane[lane], g_rt.lane_ev[lane], 0));
+  }
+  return 0;
+}
+int ndsmk_lane_sync(int lane) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(lane >= 0 && lane < NDSMK_LANES && g_rt.lane[lane]);
+  NDSM_HIP(hipStreamSynchronize(g_rt.lane[lane]));
   return 0;
 }
 

@@ -21,8 +21,12 @@
 // rbgs3_color (smooth.hip), residual3 (residual.hip), restrict_k<3> / prolong_add_k<3> (transfer.hip),
 // solve_exact_k (coarse.hip) - and -ffp-contract=off: bit-identical to the level-by-level path
 // (tests/test_gpu_parity.py::test_tail_cycle_bitwise and every V-cycle test: the default path runs it).
-// The one order-dependent sum, solve_exact's MEAN metric, is formed exactly as solve_exact_k forms it:
-// by the first 256 threads, strided by 256, four wave partials.
+// The order-dependent sums - solve_exact's MEAN metric and, on the all-Neumann 2-D hierarchies of the face
+// solves, the mean that is subtracted after every sweep - are formed exactly as the kernels they stand in for
+// form them: solve_exact_k's by the first 256 threads, strided by 256, four wave partials; rbgs2_small's by all
+// 1024 threads, strided by 1024, sixteen wave partials in order.
+// 2-D hierarchies (ndim = 2) take the same path with the five-point expressions of rbgs2_small / residual2 /
+// restrict_k<2> / prolong_add_k<2>: a 512^2 face has five such levels (64^2 ... 4^2), a 128^2 face all but one.
 #include "common.hpp"
 
 #include <cstdlib>
@@ -31,7 +35,7 @@ namespace {
 
 constexpr int kT = 1024;       // threads
 constexpr int kQ = 3;          // points per thread and colour: up to 3072 updates per colour pass
-constexpr int kMaxLev = 4;
+constexpr int kMaxLev = 6;
 constexpr int kMaxTop = 6144;  // points of the finest tail level
 constexpr int kMaxExact = 2048;  // points of the coarsest grid (solve_exact_k's limit: same coverage)
 constexpr int kRT = 6;         // restriction taps per dimension (any mesh ratio >= 2)
@@ -111,15 +115,56 @@ __device__ __forceinline__ void colour_pass(char *ldsb, const ndsmk_grid &g, con
   __syncthreads();
 }
 
+// 2-D (ndsm_poisson.f90:603-617; the expression of rbgs2_small / rbgs2_color - the point sets are the 3-D ones
+// with one plane: stencil_stride's collapsed boundary neighbours are the mirrored ones)
+__device__ __forceinline__ void colour_pass2(char *ldsb, const ndsmk_grid &g, const PtSet &s) {
+#define LD(off) (*reinterpret_cast<const double *>(ldsb + (off)))
+#pragma unroll
+  for (int q = 0; q < kQ; ++q) {
+    if (s.c[q] >= 0) {
+      double un = 0.0;
+      un = un + LD(s.xl[q]) * g.w[0] + LD(s.xh[q]) * g.w[0];
+      un = un + LD(s.yl[q]) * g.w[1] + LD(s.yh[q]) * g.w[1];
+      *reinterpret_cast<double *>(ldsb + s.c[q]) = (un - s.rv[q]) * g.w1;
+    }
+  }
+#undef LD
+  __syncthreads();
+}
+
+// u -= mean(u) after a sweep of an all-Neumann problem (ndsm_poisson.f90:534-547), summed as rbgs2_small /
+// rbgs2_medium sum it: per thread strided by the workgroup, a shuffle tree per wave, the 16 wave partials in order
+__device__ __forceinline__ void mean_shift(double *u, int n, double *red16) {
+  double sm = 0.0;
+  for (int p = (int)threadIdx.x; p < n; p += kT) sm = sm + u[p];
+  for (int o = 32; o > 0; o >>= 1) sm = sm + __shfl_down(sm, o, 64);
+  if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = sm;
+  __syncthreads();
+  double tot = 0.0;
+  for (int q = 0; q < kT / 64; ++q) tot = tot + red16[q];
+  const double mean = tot / (double)n;
+  for (int p = (int)threadIdx.x; p < n; p += kT) u[p] = u[p] - mean;
+  __syncthreads();
+}
+
 // nsweeps sweeps of the level whose u / rhs start at doubles u_off / rhs_off of the LDS array
-__device__ __forceinline__ void relax(double *lds, int u_off, int rhs_off, const ndsmk_grid &g, int nsweeps) {
+__device__ __forceinline__ void relax(double *lds, int u_off, int rhs_off, const ndsmk_grid &g, int nsweeps, double *red16) {
   PtSet a, b;
   make_set(g, g.first_par & 1, u_off, lds + rhs_off, a);
   make_set(g, (g.first_par + 1) & 1, u_off, lds + rhs_off, b);
   char *const ldsb = reinterpret_cast<char *>(lds);
-  for (int sw = 0; sw < nsweeps; ++sw) {
-    colour_pass(ldsb, g, a);
-    colour_pass(ldsb, g, b);
+  if (g.ndim == 3) {
+    for (int sw = 0; sw < nsweeps; ++sw) {
+      colour_pass(ldsb, g, a);
+      colour_pass(ldsb, g, b);
+    }
+  } else {
+    const int n = g.n[0] * g.n[1];
+    for (int sw = 0; sw < nsweeps; ++sw) {
+      colour_pass2(ldsb, g, a);
+      colour_pass2(ldsb, g, b);
+      if (g.all_neumann) mean_shift(lds + u_off, n, red16);
+    }
   }
 }
 
@@ -128,6 +173,27 @@ __device__ __forceinline__ void residual(const double *u, const double *rhs, dou
   const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
   const int n = nx * ny * nz;
   const int sy = nx, sz = nx * ny;
+  if (g.ndim == 2) {  // residual2 (ndsm_poisson.f90:280-353): rhs - sum_d (u_lo - 2u + u_hi) w_d
+    for (int c = (int)threadIdx.x; c < n; c += kT) {
+      const int i = c % nx, j = c / nx;
+      const bool inside = i >= g.lb[0] && i <= g.ub[0] && j >= g.lb[1] && j <= g.ub[1];
+      double out = 0.0;
+      if (inside) {
+        const double uc = u[c];
+        const double xl = u[i == 0 ? c + 1 : (i == nx - 1 ? c - 1 : c - 1)];
+        const double xh = u[i == 0 ? c + 1 : (i == nx - 1 ? c - 1 : c + 1)];
+        const double yl = u[j == 0 ? c + sy : (j == ny - 1 ? c - sy : c - sy)];
+        const double yh = u[j == 0 ? c + sy : (j == ny - 1 ? c - sy : c + sy)];
+        double lap = 0.0;  // ndsm_poisson.f90:334-345
+        lap = lap + (xl - 2 * uc + xh) * g.w[0];
+        lap = lap + (yl - 2 * uc + yh) * g.w[1];
+        out = rhs[c] - lap;
+      }
+      r[c] = out;
+    }
+    __syncthreads();
+    return;
+  }
   for (int c = (int)threadIdx.x; c < n; c += kT) {
     const int i = c % nx, j = (c / nx) % ny, k = c / (nx * ny);
     const bool inside = i >= g.lb[0] && i <= g.ub[0] && j >= g.lb[1] && j <= g.ub[1] && k >= g.lb[2] && k <= g.ub[2];
@@ -154,6 +220,40 @@ __device__ __forceinline__ void restrict_to(const double *f, double *rhs_c, doub
   const int ncx = gc.n[0], ncy = gc.n[1], ncz = gc.n[2];
   const int nc = ncx * ncy * ncz;
   const int sy = gf.n[0], sz = gf.n[0] * gf.n[1];
+  if (gf.ndim == 2) {  // restrict_k<2>
+    for (int c = (int)threadIdx.x; c < nc; c += kT) {
+      const int I = c % ncx, J = c / ncx;
+      const int i0 = TAB(int32_t, x.o_rlo[0])[I], ni = TAB(int32_t, x.o_rcnt[0])[I];
+      const int j0 = TAB(int32_t, x.o_rlo[1])[J], nj = TAB(int32_t, x.o_rcnt[1])[J];
+      const double *cx = TAB(double, x.o_rw[0]) + I * x.maxt[0];
+      const double *cy = TAB(double, x.o_rw[1]) + J * x.maxt[1];
+      double wx[kRT], wy[kRT];
+#pragma unroll
+      for (int q = 0; q < kRT; ++q) {
+        wx[q] = q < ni ? cx[q] : 0.0;
+        wy[q] = q < nj ? cy[q] : 0.0;
+      }
+      double fc = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < kRT; ++jj) {
+        if (jj < nj) {
+          const double *row = f + i0 + sy * (j0 + jj);
+#pragma unroll
+          for (int ii = 0; ii < kRT; ++ii) {
+            if (ii < ni) {
+              double w = wx[ii] * x.w2[0];
+              w = w * wy[jj] * x.w2[1];
+              fc = fc + w * row[ii];
+            }
+          }
+        }
+      }
+      rhs_c[c] = fc;
+      u_c[c] = 0.0;
+    }
+    __syncthreads();
+    return;
+  }
   for (int c = (int)threadIdx.x; c < nc; c += kT) {
     const int I = c % ncx, J = (c / ncx) % ncy, K = c / (ncx * ncy);
     const int i0 = TAB(int32_t, x.o_rlo[0])[I], ni = TAB(int32_t, x.o_rcnt[0])[I];
@@ -206,6 +306,22 @@ __device__ __forceinline__ void prolong_add(const double *uc, double *uf, const 
   const int nx = gf.n[0], ny = gf.n[1];
   const int n = nx * ny * gf.n[2];
   const int sy = gc.n[0], sz = gc.n[0] * gc.n[1];
+  if (gf.ndim == 2) {  // prolong_add_k<2>
+    for (int c = (int)threadIdx.x; c < n; c += kT) {
+      const int i = c % nx, j = c / nx;
+      const int il = TAB(int32_t, x.o_plo[0])[i], jl = TAB(int32_t, x.o_plo[1])[j];
+      const double wlx = TAB(double, x.o_pwl[0])[i], whx = TAB(double, x.o_pwh[0])[i];
+      const double wly = TAB(double, x.o_pwl[1])[j], why = TAB(double, x.o_pwh[1])[j];
+      const double *p = uc + il + sy * jl;
+      double f0 = p[0], f1 = p[1], f2 = p[sy], f3 = p[sy + 1];
+      f0 = why * f0 + wly * f2;
+      f1 = why * f1 + wly * f3;
+      const double v = whx * f0 + wlx * f1;
+      uf[c] = uf[c] + v;
+    }
+    __syncthreads();
+    return;
+  }
   for (int c = (int)threadIdx.x; c < n; c += kT) {
     const int i = c % nx, j = (c / nx) % ny, k = c / (nx * ny);
     const int il = TAB(int32_t, x.o_plo[0])[i], jl = TAB(int32_t, x.o_plo[1])[j], kl = TAB(int32_t, x.o_plo[2])[k];
@@ -264,8 +380,24 @@ __device__ __forceinline__ int exact(double *lds, int u_off, int rhs_off, double
       *conv = 1;
       break;
     }
-    colour_pass(ldsb, g, a);
-    colour_pass(ldsb, g, b);
+    if (g.ndim == 3) {
+      colour_pass(ldsb, g, a);
+      colour_pass(ldsb, g, b);
+    } else {
+      colour_pass2(ldsb, g, a);
+      colour_pass2(ldsb, g, b);
+    }
+    if (g.all_neumann) {  // solve_exact_k: s strided by its 256 threads, block_sum of four waves
+      double s = 0.0, dummy = 0.0;
+      if (act)
+        for (int p = (int)threadIdx.x; p < n; p += kXT) s = s + u[p];
+      xmaxsum(dummy, s, red);
+      const double mean = s / (double)n;
+      double *uw = lds + u_off;
+      if (act)
+        for (int p = (int)threadIdx.x; p < n; p += kXT) uw[p] = uw[p] - mean;
+      __syncthreads();
+    }
     double mx = 0.0, sm = 0.0;
     if (act) {
       for (int p = (int)threadIdx.x; p < n; p += kXT) {
@@ -284,7 +416,7 @@ __device__ __forceinline__ int exact(double *lds, int u_off, int rhs_off, double
 
 __global__ __launch_bounds__(kT) void tail_cycle_k(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ double red[8];
+  __shared__ double red[16];
   const int L = a.nlev;
   const char *const ldsb = reinterpret_cast<const char *>(lds);
   for (int q = 0; q + 1 < L; ++q)   // the transfer tables
@@ -302,7 +434,7 @@ __global__ __launch_bounds__(kT) void tail_cycle_k(TailArgs a) {
   }
   for (int q = 0; q + 1 < L; ++q) {
     TICK();
-    relax(lds, a.off_u[q], a.off_rhs[q], a.g[q], a.ms);
+    relax(lds, a.off_u[q], a.off_rhs[q], a.g[q], a.ms, red);
     TICK();
     residual(lds + a.off_u[q], lds + a.off_rhs[q], lds + a.off_r, a.g[q]);
     TICK();
@@ -313,12 +445,12 @@ __global__ __launch_bounds__(kT) void tail_cycle_k(TailArgs a) {
   const int sweeps = exact(lds, a.off_u[L - 1], a.off_rhs[L - 1], lds + a.off_sav, a.g[L - 1], a.ex_tol, a.use_max,
                            a.nmax, red, &conv);
   TICK();
-  relax(lds, a.off_u[L - 1], a.off_rhs[L - 1], a.g[L - 1], a.ms);
+  relax(lds, a.off_u[L - 1], a.off_rhs[L - 1], a.g[L - 1], a.ms, red);
   for (int q = L - 1; q >= 1; --q) {
     TICK();
     prolong_add(lds + a.off_u[q], lds + a.off_u[q - 1], a.g[q - 1], a.g[q], a.x[q - 1], ldsb);
     TICK();
-    relax(lds, a.off_u[q - 1], a.off_rhs[q - 1], a.g[q - 1], 2 * a.ms);
+    relax(lds, a.off_u[q - 1], a.off_rhs[q - 1], a.g[q - 1], 2 * a.ms, red);
   }
   TICK();
   // every level goes home (the coarser ones are only ever looked at by tests and tools)
@@ -356,6 +488,7 @@ void blob_of(const ndsmk_xfer &x, const char **base, size_t *len) {
     if (!hi || e > hi) hi = e;
   };
   for (int d = 0; d < 3; ++d) {
+    if (!x.plo[d]) continue;   // (2-D: no z tables)
     span(x.plo[d], sizeof(int32_t) * (size_t)x.nf[d]);
     span(x.pwl[d], sizeof(double) * (size_t)x.nf[d]);
     span(x.pwh[d], sizeof(double) * (size_t)x.nf[d]);
@@ -380,7 +513,7 @@ bool plan(int nlev, const ndsmk_grid *g, const ndsmk_xfer *x, TailArgs *a, size_
     t.blob_dbl = (int)(len / 8);
     t.toff = off;
     for (int d = 0; d < 3; ++d) {
-      auto o = [&](const void *p) { return (int)(8 * (size_t)off + (size_t)(static_cast<const char *>(p) - base)); };
+      auto o = [&](const void *p) { return p ? (int)(8 * (size_t)off + (size_t)(static_cast<const char *>(p) - base)) : 0; };
       t.maxt[d] = x[q].maxt[d];
       t.w2[d] = x[q].w2[d];
       t.o_plo[d] = o(x[q].plo[d]);
@@ -412,9 +545,13 @@ bool plan(int nlev, const ndsmk_grid *g, const ndsmk_xfer *x, TailArgs *a, size_
 bool applies(int nlev, const ndsmk_grid *g, const ndsmk_xfer *x) {
   if (!tail_enabled() || g_tail_off) return false;
   if (nlev < 2 || nlev > kMaxLev) return false;
+  const int ndim = g[0].ndim;
+  if (ndim != 2 && ndim != 3) return false;
   for (int q = 0; q < nlev; ++q) {
-    if (g[q].ndim != 3 || g[q].all_neumann || !whole(g[q])) return false;
-    for (int d = 0; d < 3; ++d)
+    // (3-D all-Neumann levels shift the mean with the two-stage kernels of reduce.hip: not reproduced here)
+    if (g[q].ndim != ndim || (ndim == 3 && g[q].all_neumann) || !whole(g[q])) return false;
+    if (ndim == 2 && g[q].n[2] != 1) return false;
+    for (int d = 0; d < ndim; ++d)
       if (g[q].n[d] < 2 || g[q].lb[d] < 0 || g[q].ub[d] > g[q].n[d] - 1) return false;
     const int64_t n = (int64_t)g[q].n[0] * g[q].n[1] * g[q].n[2];
     if (n > kMaxTop) return false;
@@ -423,7 +560,7 @@ bool applies(int nlev, const ndsmk_grid *g, const ndsmk_xfer *x) {
   }
   if ((int64_t)g[nlev - 1].n[0] * g[nlev - 1].n[1] * g[nlev - 1].n[2] > kMaxExact) return false;
   for (int q = 0; q + 1 < nlev; ++q) {
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < ndim; ++d) {
       if (x[q].nf[d] != g[q].n[d] || x[q].nc[d] != g[q + 1].n[d]) return false;
       if (x[q].maxt[d] < 1 || x[q].maxt[d] > kRT) return false;
       if (!x[q].plo[d] || !x[q].pwl[d] || !x[q].pwh[d] || !x[q].rlo[d] || !x[q].rcnt[d] || !x[q].rw[d]) return false;

@@ -175,6 +175,38 @@ module ndsmh_iface
       integer(c_int) :: ok
     end function
 
+    function ndsmk_select_lane(lane) bind(c, name="ndsmk_select_lane") result(rc)
+      import :: c_int
+      integer(c_int), value :: lane
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_lane_fence(lane, to_main) bind(c, name="ndsmk_lane_fence") result(rc)
+      import :: c_int
+      integer(c_int), value :: lane, to_main
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_lane_sync(lane) bind(c, name="ndsmk_lane_sync") result(rc)
+      import :: c_int
+      integer(c_int), value :: lane
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_diff_metrics_begin(a, b, n, copy) bind(c, name="ndsmk_diff_metrics_begin") result(rc)
+      import :: c_ptr, c_int64_t, c_int
+      type(c_ptr), value :: a, b
+      integer(c_int64_t), value :: n
+      integer(c_int), value :: copy
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_diff_metrics_end(out2) bind(c, name="ndsmk_diff_metrics_end") result(rc)
+      import :: c_int, c_double
+      real(c_double), intent(out) :: out2(2)
+      integer(c_int) :: rc
+    end function
+
     function ndsmk_select_stream(which) bind(c, name="ndsmk_select_stream") result(rc)
       import :: c_int
       integer(c_int), value :: which

@@ -25,6 +25,7 @@ module ndsmh_mg
   private
 
   public :: mg_solver, mg_create, mg_destroy, mg_vcycle, mg_solve
+  public :: mg_solve_lanes
   public :: mg_mixed_applies, mg_relax_window, mg_swap_u, mg_window_prolong_ok, mg_window_metric_ok
   public :: mg_set_u, mg_set_rhs, mg_get_u, mg_zero_rhs, mg_level_ptr, mg_op, mg_read_info
   public :: mg_mark_rhs_set
@@ -608,13 +609,13 @@ contains
     integer, intent(in) :: ltop
     integer :: lt
     integer :: l, q, nlev
-    type(ndsmk_grid) :: gg(4)
-    type(ndsmk_xfer) :: xx(3)
+    type(ndsmk_grid) :: gg(6)
+    type(ndsmk_xfer) :: xx(5)
     lt = s%ngrids + 1
-    if (s%ndim /= 3 .or. .not. s%has_coarse) return
+    if (.not. s%has_coarse) return
     do l = max(2, ltop + 1), s%ngrids - 1           ! (the kernel needs two levels)
       nlev = s%ngrids - l + 1
-      if (nlev > 4) cycle
+      if (nlev > 6) cycle
       do q = 1, nlev
         gg(q) = s%lev(l + q - 1)%g
         if (q < nlev) xx(q) = s%xf(l + q - 1)%x
@@ -631,9 +632,9 @@ contains
     integer, intent(in) :: lt
     integer(c_int) :: rc
     integer :: q, nlev
-    type(ndsmk_grid) :: gg(4)
-    type(ndsmk_xfer) :: xx(3)
-    type(c_ptr) :: uu(4), rr(4)
+    type(ndsmk_grid) :: gg(6)
+    type(ndsmk_xfer) :: xx(5)
+    type(c_ptr) :: uu(6), rr(6)
     nlev = s%ngrids - lt + 1
     do q = 1, nlev
       gg(q) = s%lev(lt + q - 1)%g
@@ -859,6 +860,72 @@ contains
     end do
     du_last = du
     rc = 0
+  end function
+
+  ! Several INDEPENDENT solves in lockstep, solver l on lane l-1 (ndsmk_select_lane): per round every
+  ! solve that has not converged yet enqueues one V-cycle + its metric on its own stream, then the metrics
+  ! are collected.  Small problems (the six 2-D face solves of the vector potential) are dispatch latency
+  ! and one host round trip per cycle when run one after the other; side by side the device overlaps them.
+  ! Each solve runs exactly the kernels mg_solve would have run for it, in the same order: same bits, same
+  ! cycle counts.  Solvers that would take mg_solve's tracked or mixed path are not accepted.
+  ! Before the call: whatever the solves read (right-hand sides, initial guesses) was enqueued on the MAIN
+  ! stream; after it the main stream has waited for every lane.
+  function mg_solve_lanes(ss, vc_tol, nmax, du_last, ncycles, ierr) result(rc)
+    type(mg_solver), intent(inout) :: ss(:)
+    real(wp), intent(in) :: vc_tol
+    integer, intent(in) :: nmax
+    real(wp), intent(out) :: du_last(:)
+    integer, intent(out) :: ncycles(:), ierr(:)
+    integer(c_int) :: rc, rc2
+    logical :: active(size(ss))
+    real(wp) :: met(2), du
+    integer :: it, l, nl
+
+    nl = size(ss)
+    rc = NDSMK_EARG
+    if (nl < 1 .or. nl > 6 .or. size(du_last) < nl .or. size(ncycles) < nl .or. size(ierr) < nl) return
+    do l = 1, nl
+      if (mg_mixed_applies(ss(l)) .or. mg_track_applies(ss(l)) .or. ss(l)%slab) return
+    end do
+    du_last(1:nl) = huge(du); ncycles(1:nl) = 0; ierr(1:nl) = 1
+    active = .true.
+    do l = 1, nl
+      rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800
+      rc = ndsmk_lane_fence(int(l - 1, c_int), 0_c_int); if (rc /= 0) goto 800
+      ! the caller's array is the "previous iterate" of the first comparison (:122)
+      rc = ndsmk_d2d(ss(l)%prev, ss(l)%dl(1)%u, int(ss(l)%npts1, c_size_t) * R8); if (rc /= 0) goto 800
+    end do
+    do it = 1, nmax
+      do l = 1, nl
+        if (.not. active(l)) cycle
+        rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800
+        rc = mg_vcycle(ss(l)); if (rc /= 0) goto 800
+        rc = ndsmk_diff_metrics_begin(ss(l)%dl(1)%u, ss(l)%prev, ss(l)%npts1, 1_c_int); if (rc /= 0) goto 800
+      end do
+      do l = 1, nl
+        if (.not. active(l)) cycle
+        rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800
+        rc = ndsmk_diff_metrics_end(met); if (rc /= 0) goto 800
+        if (ss(l)%use_max) then
+          du = met(1)
+        else
+          du = met(2) / real(ss(l)%npts1, wp)
+        end if
+        ncycles(l) = it
+        du_last(l) = du
+        if (du < vc_tol) then         ! strict (:136)
+          ierr(l) = 0
+          active(l) = .false.
+        end if
+      end do
+      if (.not. any(active)) exit
+    end do
+    rc = 0
+800 continue
+    rc2 = ndsmk_select_lane(-1_c_int)
+    do l = 1, nl
+      rc2 = ndsmk_lane_fence(int(l - 1, c_int), 1_c_int)
+    end do
   end function
 
   ! ------------------------------------------------------------------

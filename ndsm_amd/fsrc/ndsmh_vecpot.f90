@@ -77,8 +77,8 @@ module ndsmh_vecpot
     integer(c_int32_t) :: n3(3) = 0
     integer :: ngr = 0
     real(wp), allocatable :: qx(:), qy(:), qz(:)
-    type(mg_solver) :: s3, s2(3)
-    logical :: live3 = .false., live2(3) = .false.
+    type(mg_solver) :: s3, s2(6)            ! one 2-D hierarchy per face: the six face solves run side by side
+    logical :: live3 = .false., live2(6) = .false.
     type(c_ptr) :: dA = c_null_ptr, dB = c_null_ptr, dmesh = c_null_ptr
     type(c_ptr) :: dbn = c_null_ptr, dchi = c_null_ptr, dphi = c_null_ptr   ! packed faces: B.n, chi; six fluxes
     type(c_ptr) :: hbn = c_null_ptr                                         ! pinned staging of the six faces
@@ -279,7 +279,7 @@ contains
     rc = ndsmk_bg_drain()
     if (ctx%live3) call mg_destroy(ctx%s3)
     ctx%live3 = .false.
-    do p = 1, 3
+    do p = 1, 6
       if (ctx%live2(p)) call mg_destroy(ctx%s2(p))
       ctx%live2(p) = .false.
     end do
@@ -325,11 +325,10 @@ contains
     rc = ndsmk_h2d(dptr_offset(ctx%dmesh, off_y), c_loc(ctx%qy), int(n3(2), c_size_t) * 8_c_size_t); if (rc /= 0) return
     rc = ndsmk_h2d(dptr_offset(ctx%dmesh, off_z), c_loc(ctx%qz), int(n3(3), c_size_t) * 8_c_size_t); if (rc /= 0) return
     bc2 = 'N'
-    do pair = 1, 3
-      f = 2 * pair - 1
+    do f = 1, 6
       qa => ctx_axis(ctx, face_t1(f)); qb => ctx_axis(ctx, face_t2(f))
       fshape = [n3(face_t1(f)), n3(face_t2(f)), 1_c_int32_t]
-      rc = mg_create(ctx%s2(pair), 2, fshape, qa, qb, qb, bc2, ngr); ctx%live2(pair) = .true.
+      rc = mg_create(ctx%s2(f), 2, fshape, qa, qb, qb, bc2, ngr); ctx%live2(f) = .true.
       if (rc /= 0) return
     end do
   end function
@@ -417,7 +416,10 @@ contains
     real(wp), target :: phi(6)
     real(wp), pointer, contiguous :: hA(:, :, :, :), hB(:, :, :, :), stage(:)
     integer(c_int32_t) :: n3(3)
-    integer :: f, c, i, pair, ierr2d, ierr3d, ncyc, st
+    integer :: f, c, i, ierr2d, ierr3d, ncyc, st
+    integer :: ncyc6(6), ierr6(6)
+    real(wp) :: du6(6)
+    character(len=8) :: envbuf
     integer(ik) :: sweeps, bad, npts, cnt
     integer(c_int) :: tick_up(3), tick, zero_flag, rcb
     logical :: use_max, resident, host_faces, late_balance
@@ -513,29 +515,42 @@ contains
 
       ! ---- 2. chi on every face: 2-D all-Neumann solves, right-hand side and result stay in HBM ----
       call say(me, "Solve BVP on each boundary...")
+      ! The six problems are independent (:338-365 solves them one after the other) and each is dispatch
+      ! latency plus one host round trip per V-cycle: they run in lockstep on six streams (mg_solve_lanes;
+      ! every solve executes the kernels it would execute alone, in the same order - same bits).
+      ! NDSM_HIP_FACE_LANES=0: one after the other (A/B testing).
       ierr2d = 0
-      do pair = 1, 3
-        associate (s2 => ctx%s2(pair))
+      do f = 1, 6
+        associate (s2 => ctx%s2(f))
           s2%ms = int(iopt(IOPT_MS)); s2%ex_tol = ropt(ROPT_CTOL); s2%use_max = use_max
           s2%nmax_exact = int(iopt(IOPT_NMAXEX))
-          do f = 2 * pair - 1, 2 * pair
-            rhs2 = mg_level_ptr(s2, 1, MG_BUF_RHS, cnt)
-            u2 = mg_level_ptr(s2, 1, MG_BUF_U, cnt)
-            rc = ndsmk_face_rhs(ctx%dbn, n3, int(f - 1, c_int), ctx%dphi, area(f), rhs2); if (rc /= 0) goto 900
-            call mg_mark_rhs_set(s2)
-            rc = ndsmk_fill0(u2, int(cnt, c_size_t) * 8_c_size_t); if (rc /= 0) goto 900
-            rc = mg_reset_info(s2); if (rc /= 0) goto 900
-            rc = mg_solve(s2, ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du_last, ncyc, ierr2d)
-            if (rc /= 0) goto 900
-            u2 = mg_level_ptr(s2, 1, MG_BUF_U, cnt)                  ! (the solver swaps its buffers)
-            rc = ndsmk_d2d(dptr_offset(ctx%dchi, int(ctx%foff(f), c_size_t) * 8_c_size_t), u2, int(cnt, c_size_t) * 8_c_size_t)
-            if (rc /= 0) goto 900
-            if (ierr2d /= 0) print *, "Warning: IOPT_NCYCLES exceeded. V-cycle iteration may not have converged"
-            if (mg_read_info(s2, sweeps, bad) == 0) then
-              if (bad > 0) print *, "Warning: IOPT_NMAXEX exceeded. Coarse-mesh solution may not have converged"
-            end if
-          end do
+          rhs2 = mg_level_ptr(s2, 1, MG_BUF_RHS, cnt)
+          u2 = mg_level_ptr(s2, 1, MG_BUF_U, cnt)
+          rc = ndsmk_face_rhs(ctx%dbn, n3, int(f - 1, c_int), ctx%dphi, area(f), rhs2); if (rc /= 0) goto 900
+          call mg_mark_rhs_set(s2)
+          rc = ndsmk_fill0(u2, int(cnt, c_size_t) * 8_c_size_t); if (rc /= 0) goto 900
+          rc = mg_reset_info(s2); if (rc /= 0) goto 900
         end associate
+      end do
+      call get_environment_variable("NDSM_HIP_FACE_LANES", envbuf, status=st)
+      if (st == 0 .and. envbuf(1:1) == "0") then
+        do f = 1, 6
+          rc = mg_solve(ctx%s2(f), ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du6(f), ncyc6(f), ierr6(f))
+          if (rc /= 0) goto 900
+        end do
+      else
+        rc = mg_solve_lanes(ctx%s2, ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du6, ncyc6, ierr6)
+        if (rc /= 0) goto 900
+      end if
+      do f = 1, 6
+        u2 = mg_level_ptr(ctx%s2(f), 1, MG_BUF_U, cnt)                  ! (the solver swaps its buffers)
+        rc = ndsmk_d2d(dptr_offset(ctx%dchi, int(ctx%foff(f), c_size_t) * 8_c_size_t), u2, int(cnt, c_size_t) * 8_c_size_t)
+        if (rc /= 0) goto 900
+        ierr2d = ierr6(f)
+        if (ierr2d /= 0) print *, "Warning: IOPT_NCYCLES exceeded. V-cycle iteration may not have converged"
+        if (mg_read_info(ctx%s2(f), sweeps, bad) == 0) then
+          if (bad > 0) print *, "Warning: IOPT_NMAXEX exceeded. Coarse-mesh solution may not have converged"
+        end if
       end do
       call say(me, "Compute vector potential boundary conditions...")
     end if

@@ -1343,6 +1343,47 @@ def test_tail_cycle_bitwise(hip, ns):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ns", ([64, 64], [128, 96], [40, 136], [33, 22], [512, 512], [70, 9]), ids=_tag)
+def test_tail_cycle_bitwise_2d(hip, ns):
+    """the same for the 2-D hierarchies of the face solves (five-point expressions; on all-Neumann problems the
+    mean is subtracted after every sweep, summed in rbgs2_small's order, and inside the coarsest-grid solve in
+    solve_exact_k's): V-cycles, every level, counters and a solve history with the single launch switched off
+    and on - bit for bit"""
+    L = hip.load_library()
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u, rhs = rand_field(shp, 17), rand_field(shp, 18)
+    rhs = rhs - rhs.mean()
+
+    def run(bcs, ms, du_max):
+        S = hip.MGSolver(ns, mesh, bcs, ms=ms, du_max=du_max)
+        S.upload(1, hip.BUF_U, u)
+        S.upload(1, hip.BUF_RHS, rhs)
+        S.vcycle(2)
+        lev = [(S.download(l, hip.BUF_U), S.download(l, hip.BUF_RHS)) for l in range(1, S.ngrids + 1)]
+        info = S.info()
+        res = S.solve(vc_tol=1e-9, nmax=6, hist_len=8)
+        out = S.download(1, hip.BUF_U)
+        S.close()
+        return lev, info, (res[0], res[1], res[2], list(res[3])), out
+
+    try:
+        for bcs, ms, du_max in (("NNNN", 5, True), ("NNNN", 2, False), ("NDDN", 5, True), ("DDDD", 3, False), ("DNND", 1, True)):
+            L.ndsm_hip_debug_tail(0)
+            want = run(bcs, ms, du_max)
+            L.ndsm_hip_debug_tail(1)
+            got = run(bcs, ms, du_max)
+            for l, (a, b) in enumerate(zip(want[0], got[0]), start=1):
+                assert np.array_equal(a[0], b[0]), (bcs, "u", l)
+                assert np.array_equal(a[1], b[1]), (bcs, "rhs", l)
+            assert want[1] == got[1], (bcs, want[1], got[1])
+            assert want[2] == got[2], (bcs, want[2], got[2])
+            assert np.array_equal(want[3], got[3]), bcs
+    finally:
+        L.ndsm_hip_debug_tail(1)
+
+
+@pytest.mark.gpu
 def test_baseline_config4_full_grid_mixed_component(hip):
     """BASELINE config[4]'s grid at FULL size - 2048 x 2048 x 1024 = 2^32 points, 32 GiB per fp64 array - and
     in its precision mode (fp32 smoother / fp64 residual): two solve-loop cycles of ONE component (Ay's
