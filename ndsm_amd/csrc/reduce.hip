@@ -123,9 +123,14 @@ __global__ __launch_bounds__(kRedBlock) void sum_stage1(const double *__restrict
   }
 }
 
-__global__ __launch_bounds__(kRedBlock) void mean_stage2(const double *__restrict__ part, int nblocks, int64_t n,
-                                                         double *__restrict__ mean_out) {
+// second stage of the mean + the subtraction in one launch: EVERY block folds the partials of sum_stage1 in index
+// order with the same strides and the same tree (the same bits in every block, and the bits a single folding
+// block followed by a subtraction kernel gave), then subtracts over its grid-stride range.  One launch less per
+// sweep of an all-Neumann level; nb <= 2048 partials are L2 hits.
+__global__ __launch_bounds__(kRedBlock) void mean_shift_k(double *__restrict__ u, int64_t n, const double *__restrict__ part,
+                                                          int nblocks) {
   __shared__ double ssm[kRedBlock / 64];
+  __shared__ double s_mean;
   double sm = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += blockDim.x) sm = sm + part[i];
   sm = wave_sum(sm);
@@ -135,13 +140,10 @@ __global__ __launch_bounds__(kRedBlock) void mean_stage2(const double *__restric
   if (threadIdx.x == 0) {
     double s = ssm[0];
     for (int w = 1; w < kRedBlock / 64; ++w) s = s + ssm[w];
-    mean_out[0] = s / (double)n;
+    s_mean = s / (double)n;
   }
-}
-
-__global__ __launch_bounds__(kRedBlock) void shift_k(double *__restrict__ u, int64_t n,
-                                                     const double *__restrict__ mean) {
-  const double m = mean[0];
+  __syncthreads();
+  const double m = s_mean;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) u[i] = u[i] - m;
 }
@@ -161,12 +163,9 @@ int launch_mean_shift(double *u, int64_t n) {
   if (int rc = ensure_scratch()) return rc;
   const int nb = nblocks_for(n);
   hipStream_t s = stream();
-  double *mean = g_s.d_part + 2 * kRedMaxBlocks;
   hipLaunchKernelGGL(sum_stage1, dim3(nb), dim3(kRedBlock), 0, s, u, n, g_s.d_part);
   NDSM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(mean_stage2, dim3(1), dim3(kRedBlock), 0, s, g_s.d_part, nb, n, mean);
-  NDSM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(shift_k, dim3(nb), dim3(kRedBlock), 0, s, u, n, mean);
+  hipLaunchKernelGGL(mean_shift_k, dim3(nb), dim3(kRedBlock), 0, s, u, n, g_s.d_part, nb);
   NDSM_LAUNCH_CHECK();
   return 0;
 }
