@@ -206,6 +206,10 @@ int ndsmk_fused_prolong_ok(const ndsmk_grid *g, const double *rhs, int nsweeps);
 int ndsmk_select_lane(int lane);           /* -1: main stream */
 int ndsmk_lane_fence(int lane, int to_main);
 int ndsmk_lane_sync(int lane);
+int ndsmk_capture_begin(void);             /* record what is enqueued on the selected lane ... */
+int ndsmk_capture_end(void **exec);        /* ... into an executable graph */
+int ndsmk_graph_launch(void *exec);        /* replay it on the selected lane / stream */
+int ndsmk_graph_destroy(void *exec);
 int ndsmk_select_stream(int which);
 int ndsmk_stream_fence(int from, int to);
 

@@ -383,6 +383,43 @@ int ndsmk_lane_fence(int lane, int to_main) {
   }
   return 0;
 }
+// Graphs: a launch-bound sequence that repeats unchanged (one V-cycle + metric of a small 2-D solve: ~190
+// launches of a few microseconds) is recorded once from the selected lane's stream and replayed as ONE graph launch.
+// ndsmk_capture_begin(): everything enqueued on the selected lane from now on is recorded, not executed;
+// ndsmk_capture_end(&exec): stop recording and instantiate; ndsmk_graph_launch(exec): replay on the selected
+// lane; ndsmk_graph_destroy(exec).  The recorded calls must not allocate, synchronise or set kernel
+// attributes: the caller runs the sequence once un-recorded first (every lazily created scratch then exists).
+int ndsmk_capture_begin(void) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(g_rt.cur_lane >= 0);
+  NDSM_HIP(hipStreamBeginCapture(g_rt.lane[g_rt.cur_lane], hipStreamCaptureModeRelaxed));
+  return 0;
+}
+int ndsmk_capture_end(void **exec) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(g_rt.cur_lane >= 0 && exec);
+  *exec = nullptr;
+  hipGraph_t g = nullptr;
+  NDSM_HIP(hipStreamEndCapture(g_rt.lane[g_rt.cur_lane], &g));
+  hipGraphExec_t e = nullptr;
+  hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  NDSM_HIP(rc);
+  *exec = (void *)e;
+  return 0;
+}
+int ndsmk_graph_launch(void *exec) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(exec);
+  NDSM_HIP(hipGraphLaunch((hipGraphExec_t)exec, ndsm::stream()));
+  return 0;
+}
+int ndsmk_graph_destroy(void *exec) {
+  if (!exec) return 0;
+  NDSM_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
+  return 0;
+}
+
 int ndsmk_lane_sync(int lane) {
   NDSM_REQUIRE_READY();
   NDSM_CHECK_ARG(lane >= 0 && lane < NDSMK_LANES && g_rt.lane[lane]);

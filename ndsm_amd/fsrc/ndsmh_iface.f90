@@ -193,6 +193,29 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_capture_begin() bind(c, name="ndsmk_capture_begin") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_capture_end(exec) bind(c, name="ndsmk_capture_end") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), intent(out) :: exec
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_graph_launch(exec) bind(c, name="ndsmk_graph_launch") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: exec
+      integer(c_int) :: rc
+    end function
+
+    function ndsmk_graph_destroy(exec) bind(c, name="ndsmk_graph_destroy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: exec
+      integer(c_int) :: rc
+    end function
+
     function ndsmk_diff_metrics_begin(a, b, n, copy) bind(c, name="ndsmk_diff_metrics_begin") result(rc)
       import :: c_ptr, c_int64_t, c_int
       type(c_ptr), value :: a, b

@@ -78,6 +78,11 @@ module ndsmh_mg
     logical :: track = .false.           ! the V-cycle in progress runs in that mode
     logical :: met_done = .false.        ! its last sweep did evaluate the metric
     type(c_ptr) :: keep = c_null_ptr     ! the kept buffer
+    ! ---- one V-cycle + metric as an executable graph (mg_solve_lanes; small solves that are launch bound) ----
+    type(c_ptr) :: graph = c_null_ptr    ! hipGraphExec_t, or null
+    type(c_ptr) :: gkey_p(3) = c_null_ptr  ! what it was recorded for: level-1 u, rhs, prev ...
+    integer :: gkey_i(5) = 0             ! ... ms, nmax_exact, use_max, first level of the tail launch, lane (its scratch)
+    real(wp) :: gkey_r = 0               ! ... ex_tol
     integer :: precision = 0             ! 0 fp64 (reference arithmetic), 1 mixed where level 1 is large enough,
                                          ! 2 mixed wherever the fp32 kernels cover level 1 (tests)
     ! ---- z-slab mode (level 1 distributed, SURVEY 8e); unused otherwise
@@ -334,8 +339,40 @@ contains
       call fill_grid_desc(s%ndim, s%lev(l), s%bcs)
     end do
     if (s%slab) call apply_slab_window(s%lev(1), s%sl)
+    call drop_graph(s)
     rc = 0
   end function
+
+  subroutine drop_graph(s)
+    type(mg_solver), intent(inout) :: s
+    integer(c_int) :: rc
+    if (c_associated(s%graph)) then
+      rc = ndsmk_sync()
+      rc = ndsmk_graph_destroy(s%graph)
+    end if
+    s%graph = c_null_ptr
+  end subroutine
+
+  ! is the recorded graph still the sequence mg_vcycle + metric would enqueue now?
+  function graph_valid(s, lane) result(ok)
+    type(mg_solver), intent(in) :: s
+    integer, intent(in) :: lane
+    logical :: ok
+    ok = c_associated(s%graph)
+    if (.not. ok) return
+    ok = c_associated(s%gkey_p(1), s%dl(1)%u) .and. c_associated(s%gkey_p(2), s%dl(1)%rhs) .and. &
+         c_associated(s%gkey_p(3), s%prev) .and. s%gkey_i(1) == s%ms .and. s%gkey_i(2) == s%nmax_exact .and. &
+         s%gkey_i(3) == merge(1, 0, s%use_max) .and. s%gkey_i(4) == tail_first(s, 1) .and. s%gkey_i(5) == lane .and. &
+         s%gkey_r == s%ex_tol
+  end function
+
+  subroutine graph_stamp(s, lane)
+    type(mg_solver), intent(inout) :: s
+    integer, intent(in) :: lane
+    s%gkey_p = [s%dl(1)%u, s%dl(1)%rhs, s%prev]
+    s%gkey_i = [s%ms, s%nmax_exact, merge(1, 0, s%use_max), tail_first(s, 1), lane]
+    s%gkey_r = s%ex_tol
+  end subroutine
 
   ! device-to-device copy of the level-1 solution into caller-owned HBM
   function mg_export_u(s, d_dst) result(rc)
@@ -360,6 +397,7 @@ contains
     type(mg_solver), intent(inout) :: s
     integer :: l
     integer(c_int) :: rc
+    call drop_graph(s)
     if (allocated(s%dl)) then
       do l = 1, size(s%dl)
         rc = ndsmk_free(s%dl(l)%u)
@@ -879,7 +917,8 @@ contains
     integer(c_int) :: rc, rc2
     logical :: active(size(ss))
     real(wp) :: met(2), du
-    integer :: it, l, nl
+    integer :: it, l, nl, st
+    logical :: graphs
 
     nl = size(ss)
     rc = NDSMK_EARG
@@ -889,6 +928,18 @@ contains
     end do
     du_last(1:nl) = huge(du); ncycles(1:nl) = 0; ierr(1:nl) = 1
     active = .true.
+    ! From the second round on a solve replays its V-cycle + metric as ONE graph launch, recorded in the second
+    ! round of the first call (the first round runs plain: every lazily created scratch exists afterwards) and
+    ! kept with the solver while its arrays and parameters stay what they were.  2-D only: those cycles are
+    ! ~190 launches of a few microseconds and nothing in them depends on the host; a 3-D level-1 array swaps
+    ! with its partner from cycle to cycle.  NDSM_HIP_NO_GRAPHS=1: always enqueue kernel by kernel (same bits).
+    call get_environment_variable("NDSM_HIP_NO_GRAPHS", status=st)
+    graphs = (st /= 0)
+    do l = 1, nl
+      ! (below ~180^2 points a cycle is a handful of launches - sweeps of a whole level and the tail are one each -
+      ! and replaying a graph costs more than it saves: 64^3 calls measured 12-13 ms without, 14.5 ms with)
+      if (ss(l)%ndim /= 2 .or. ss(l)%lev(1)%npts < 32768_ik) graphs = .false.
+    end do
     do l = 1, nl
       rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800
       rc = ndsmk_lane_fence(int(l - 1, c_int), 0_c_int); if (rc /= 0) goto 800
@@ -899,6 +950,31 @@ contains
       do l = 1, nl
         if (.not. active(l)) cycle
         rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800
+        if (graphs .and. it >= 2) then
+          if (.not. graph_valid(ss(l), l - 1)) then
+            call drop_graph(ss(l))
+            rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800   ! (drop_graph drains the device only)
+            rc = ndsmk_capture_begin()
+            if (rc == 0) then
+              rc = mg_vcycle(ss(l))
+              if (rc == 0) rc = ndsmk_diff_metrics_begin(ss(l)%dl(1)%u, ss(l)%prev, ss(l)%npts1, 1_c_int)
+              rc2 = ndsmk_capture_end(ss(l)%graph)
+              if (rc == 0) rc = rc2
+              ss(l)%vcycles_done = ss(l)%vcycles_done - 1     ! (recorded, not run: the replay below counts)
+            end if
+            if (rc /= 0) then       ! recording is an optimisation: without it the round is enqueued as usual
+              ss(l)%graph = c_null_ptr
+              graphs = .false.
+            else
+              call graph_stamp(ss(l), l - 1)
+            end if
+          end if
+          if (graphs) then
+            rc = ndsmk_graph_launch(ss(l)%graph); if (rc /= 0) goto 800
+            ss(l)%vcycles_done = ss(l)%vcycles_done + 1
+            cycle
+          end if
+        end if
         rc = mg_vcycle(ss(l)); if (rc /= 0) goto 800
         rc = ndsmk_diff_metrics_begin(ss(l)%dl(1)%u, ss(l)%prev, ss(l)%npts1, 1_c_int); if (rc /= 0) goto 800
       end do
@@ -926,6 +1002,7 @@ contains
     do l = 1, nl
       rc2 = ndsmk_lane_fence(int(l - 1, c_int), 1_c_int)
     end do
+
   end function
 
   ! ------------------------------------------------------------------

@@ -8,7 +8,7 @@ from golden_inputs import analytic_case
 for n in [int(a) for a in sys.argv[1:]] or (22, 64, 128, 256):
     x, y, z, A1, b1 = analytic_case(n)
     out = {}
-    for mode in ("0", "1", "0", "1"):
+    for mode in ("0", "1", "0", "1", "1"):
         os.environ["NDSM_HIP_FACE_LANES"] = mode
         ndsm_amd.vector_potential(x, y, z, b1)
         t = time.perf_counter(); ierr, A, B = ndsm_amd.vector_potential(x, y, z, b1); dt = time.perf_counter() - t

@@ -1384,6 +1384,46 @@ def test_tail_cycle_bitwise_2d(hip, ns):
 
 
 @pytest.mark.gpu
+def test_face_solves_side_by_side_and_replayed_bitwise(hip):
+    """the six 2-D face solves of ndsm_vector_solve: one after the other (NDSM_HIP_FACE_LANES=0), in lockstep on
+    six streams with every launch enqueued (NDSM_HIP_NO_GRAPHS=1), and in lockstep with each solve's V-cycle +
+    metric replayed as a recorded graph from its second round on (the default for faces of >= 32768 points) -
+    the same A and B bit for bit; so is a repeated call (the recorded graphs are kept with the cached context)
+    and a call after the options changed (ms, the coarsest-grid stop test: the graphs are recorded again)"""
+    import ndsm_amd
+    x, y, z, _A1, b1 = analytic_case([200, 200, 184])      # faces of 200 x 200 and 200 x 184 points
+
+    def call(**kw):
+        ierr, A, B = ndsm_amd.vector_potential(x, y, z, b1, **kw)
+        assert ierr == 0
+        return A, B
+
+    keep = {k: os.environ.get(k) for k in ("NDSM_HIP_FACE_LANES", "NDSM_HIP_NO_GRAPHS")}
+    try:
+        os.environ["NDSM_HIP_FACE_LANES"] = "0"
+        want = call()
+        want3 = call(ms=3, mean=True)
+        os.environ["NDSM_HIP_FACE_LANES"] = "1"
+        os.environ["NDSM_HIP_NO_GRAPHS"] = "1"
+        got = call()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        os.environ.pop("NDSM_HIP_NO_GRAPHS")
+        for _ in range(2):                                   # records, then replays what the first call recorded
+            got = call()
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        got3 = call(ms=3, mean=True)                         # other sweeps per level, other stop test: recorded anew
+        assert np.array_equal(got3[0], want3[0]) and np.array_equal(got3[1], want3[1])
+        got = call()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
 def test_baseline_config4_full_grid_mixed_component(hip):
     """BASELINE config[4]'s grid at FULL size - 2048 x 2048 x 1024 = 2^32 points, 32 GiB per fp64 array - and
     in its precision mode (fp32 smoother / fp64 residual): two solve-loop cycles of ONE component (Ay's
