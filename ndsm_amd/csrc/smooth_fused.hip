@@ -1043,6 +1043,9 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
         case 3: rc = launch_cfg<T, 2, 136, 22, 768, 4>(g, u, uout, rhs, tgt); break;
         case 5: rc = launch_cfg<T, 2, 72, 28, 512, 4>(g, u, uout, rhs, tgt); break;
         default:
+          // (fp32: four LDS planes are 65 KB, so two workgroups would fit a CU at <= 64 VGPRs - tried:
+          // __launch_bounds__(1024, 8) gives 64 VGPRs + 44 B of scratch and the mixed-precision cycle at 512^3
+          // goes from 6.5 to 7.9 ms; not built)
           rc = big ? (launch_cfg<T, 2, 136, 30, 1024, 4, 0, true>(g, u, uout, rhs, tgt))
                    : (launch_cfg<T, 2, 136, 30, 1024, 4>(g, u, uout, rhs, tgt));
           break;
