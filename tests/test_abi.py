@@ -163,3 +163,4 @@ def test_additive_entry_points_fail_cleanly_without_a_gpu(lib):
     import ndsm_amd
     with pytest.raises(ndsm_amd.NdsmHipError):
         ndsm_amd.VecPot(x, x, x)
+
