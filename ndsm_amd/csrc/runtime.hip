@@ -401,6 +401,10 @@ int ndsmk_capture_end(void **exec) {
   *exec = nullptr;
   hipGraph_t g = nullptr;
   NDSM_HIP(hipStreamEndCapture(g_rt.lane[g_rt.cur_lane], &g));
+  if (std::getenv("NDSM_HIP_FAKE_GRAPH_FAILURE")) {   // tests: the caller's fall-back to plain enqueueing
+    (void)hipGraphDestroy(g);
+    return ndsm::fail(NDSMK_EARG, "graph instantiation failed (simulated)", __FILE__, __LINE__);
+  }
   hipGraphExec_t e = nullptr;
   hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);

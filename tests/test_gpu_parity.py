@@ -1415,7 +1415,14 @@ def test_face_solves_side_by_side_and_replayed_bitwise(hip):
         assert np.array_equal(got3[0], want3[0]) and np.array_equal(got3[1], want3[1])
         got = call()
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        os.environ["NDSM_HIP_FAKE_GRAPH_FAILURE"] = "1"      # recording fails: the rounds are enqueued as usual
+        got3 = call(ms=2)
+        os.environ.pop("NDSM_HIP_FAKE_GRAPH_FAILURE")
+        os.environ["NDSM_HIP_FACE_LANES"] = "0"
+        want3 = call(ms=2)
+        assert np.array_equal(got3[0], want3[0]) and np.array_equal(got3[1], want3[1])
     finally:
+        os.environ.pop("NDSM_HIP_FAKE_GRAPH_FAILURE", None)
         for k, v in keep.items():
             if v is None:
                 os.environ.pop(k, None)
