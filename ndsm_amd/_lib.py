@@ -38,6 +38,10 @@ def load_library(path=None):
     # searched BEFORE the global scope.  Without it, a process that imported PyTorch first would
     # bind our hip*/nccl* calls to the second ROCm stack torch bundles (torch loads it RTLD_GLOBAL).
     mode = os.RTLD_NOW | os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0)
+    # multi-process runs (one rank per GPU, RCCL): this pool's host driver does dmabuf IPC only; without the
+    # variable RCCL's peer set-up fails with "hipIpcGetMemHandle: invalid argument".  It is read when the HSA
+    # runtime comes up, i.e. at the first HIP call below - a caller's own value is left alone.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     L = ctypes.CDLL(p, mode=mode)
     L.ndsm_vector_solve.restype = ctypes.c_int
     L.ndsm_hip_last_error.argtypes = [ctypes.c_char_p, ctypes.c_int]
