@@ -332,6 +332,10 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # one node by contract: the CPU rendezvous / control traffic stays on the loop-back interface
+            # (gloo otherwise picks the interface the host NAME resolves to - which it may not)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
