@@ -315,6 +315,36 @@ def test_pipeline_known_answer_rows(hip, n, mean):
     assert got == (RESULTS_TEST2 if mean else RESULTS_TEST1)[n]
 
 
+def test_2d_neumann_solve_error_scaling(hip):
+    """the reference's unit_test_2D_solve property (tests/unit_tests/unit_test_2D_solve.f90:63-242; stale there -
+    it no longer compiles - so re-stated, not run): the 2-D all-Neumann Poisson problem laplace(u) = a (2x - Lx)
+    + b (2y - Ly) on its 27 x 36 base mesh scaled up, zero initial guess, ms = 5, tolerance 1e-12; the solution
+    with its mean removed is a x^2 (x/3 - Lx/2) + b y^2 (y/3 - Ly/2) minus its mean.  Every solve converges and
+    the max / mean errors fall as h^2"""
+    a1, b1 = 0.3745401188473625, 0.9507143064099162
+    rows = []
+    for scale in (1.0, 1.5, 2.0, 4.0, 5.5, 10.0):
+        nx, ny = int(np.ceil(27 * scale)), int(np.ceil(36 * scale))
+        dq = 1.0 / (nx - 1)
+        x, y = np.arange(nx) * dq, np.arange(ny) * dq
+        Lx, Ly = 1.0, y.max() - y.min()
+        rhs = a1 * (2 * x[None, :] - Lx) + b1 * (2 * y[:, None] - Ly)
+        ue = a1 * x[None, :] ** 2 * (x[None, :] / 3 - Lx / 2) + b1 * y[:, None] ** 2 * (y[:, None] / 3 - Ly / 2)
+        ue = ue - ue.mean()
+        S = hip.MGSolver([nx, ny], [x, y], "NNNN", ms=5, ex_tol=1e-12)
+        S.upload(1, hip.BUF_RHS, rhs)
+        S.upload(1, hip.BUF_U, np.zeros_like(rhs))
+        ierr, du, nc, _h = S.solve(vc_tol=1e-12, nmax=256)
+        u = S.download(1, hip.BUF_U)
+        S.close()
+        assert ierr == 0 and nc < 64, (scale, ierr, nc, du)
+        rows.append((dq, np.abs(u - ue).max(), np.abs(u - ue).mean()))
+    rows = np.array(rows)
+    for k, name in ((1, "Emax"), (2, "Eavg")):
+        gamma = np.polyfit(np.log(rows[:, 0]), np.log(rows[:, k]), 1)[0]
+        assert 1.9 < gamma < 2.1, (name, gamma, rows)
+
+
 def test_pipeline_error_scaling(hip):
     """the property the reference's integration test reports (integration_test1.py:157-160, utests.py:32-65): the
     errors against the analytic field fall as a power law in the mesh spacing - second order for A, first to
