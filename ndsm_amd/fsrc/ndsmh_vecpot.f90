@@ -177,13 +177,14 @@ contains
     integer, intent(out) :: ierr2d
     integer(c_int) :: rc
     character(len=*), parameter :: me = "compute_vector_potential"
-    type(mg_solver) :: s2
-    real(wp) :: area(6), du_last, fac
-    integer :: f, i, j, ncyc, pair
+    type(mg_solver) :: s2(6)
+    real(wp) :: area(6), du6(6), fac
+    integer :: f, i, j, ncyc6(6), ierr6(6), st
     integer(ik) :: sweeps, bad
     integer(c_int32_t) :: fshape(3)
-    logical :: live2
+    logical :: live2(6)
     character(len=1) :: bc2(4)
+    character(len=8) :: envbuf
     real(wp), pointer :: qa(:), qb(:)
 
     rc = 0
@@ -196,31 +197,40 @@ contains
 
     ! ---- 2. chi on every face: 2-D all-Neumann solves on the device ---
     call say(me, "Solve BVP on each boundary...")
+    ! (one hierarchy per face, the six solves side by side: mg_solve_lanes, as in vecpot_run)
     ierr2d = 0
     bc2 = 'N'
-    do pair = 1, 3
-      f = 2 * pair - 1
+    do f = 1, 6
       qa => axis_mesh(face_t1(f)); qb => axis_mesh(face_t2(f))
       fshape = [int(fc(f)%n1, c_int32_t), int(fc(f)%n2, c_int32_t), 1_c_int32_t]
-      rc = mg_create(s2, 2, fshape, qa, qb, qb, bc2, int(iopt(IOPT_NGRIDS))); live2 = .true.
+      rc = mg_create(s2(f), 2, fshape, qa, qb, qb, bc2, int(iopt(IOPT_NGRIDS))); live2(f) = .true.
       if (rc /= 0) goto 900
-      s2%ms = int(iopt(IOPT_MS)); s2%ex_tol = ropt(ROPT_CTOL); s2%use_max = (iopt(IOPT_DUMAX) == 1)
-      s2%nmax_exact = int(iopt(IOPT_NMAXEX))
-      do f = 2 * pair - 1, 2 * pair
-        fc(f)%chi = 0
-        fc(f)%bn = fc(f)%bn - phi(f) / area(f)
-        rc = mg_set_u(s2, c_loc(fc(f)%chi)); if (rc /= 0) goto 900
-        rc = mg_set_rhs(s2, c_loc(fc(f)%bn)); if (rc /= 0) goto 900
-        rc = mg_reset_info(s2); if (rc /= 0) goto 900
-        rc = mg_solve(s2, ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du_last, ncyc, ierr2d)
+      s2(f)%ms = int(iopt(IOPT_MS)); s2(f)%ex_tol = ropt(ROPT_CTOL); s2(f)%use_max = (iopt(IOPT_DUMAX) == 1)
+      s2(f)%nmax_exact = int(iopt(IOPT_NMAXEX))
+      fc(f)%chi = 0
+      fc(f)%bn = fc(f)%bn - phi(f) / area(f)
+      rc = mg_set_u(s2(f), c_loc(fc(f)%chi)); if (rc /= 0) goto 900
+      rc = mg_set_rhs(s2(f), c_loc(fc(f)%bn)); if (rc /= 0) goto 900
+      rc = mg_reset_info(s2(f)); if (rc /= 0) goto 900
+    end do
+    call get_environment_variable("NDSM_HIP_FACE_LANES", envbuf, status=st)
+    if (st == 0 .and. envbuf(1:1) == "0") then
+      do f = 1, 6
+        rc = mg_solve(s2(f), ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du6(f), ncyc6(f), ierr6(f))
         if (rc /= 0) goto 900
-        rc = mg_get_u(s2, c_loc(fc(f)%chi)); if (rc /= 0) goto 900
-        if (ierr2d /= 0) print *, "Warning: IOPT_NCYCLES exceeded. V-cycle iteration may not have converged"
-        if (mg_read_info(s2, sweeps, bad) == 0) then
-          if (bad > 0) print *, "Warning: IOPT_NMAXEX exceeded. Coarse-mesh solution may not have converged"
-        end if
       end do
-      call mg_destroy(s2); live2 = .false.
+    else
+      rc = mg_solve_lanes(s2, ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du6, ncyc6, ierr6)
+      if (rc /= 0) goto 900
+    end if
+    do f = 1, 6
+      rc = mg_get_u(s2(f), c_loc(fc(f)%chi)); if (rc /= 0) goto 900
+      ierr2d = ierr6(f)
+      if (ierr2d /= 0) print *, "Warning: IOPT_NCYCLES exceeded. V-cycle iteration may not have converged"
+      if (mg_read_info(s2(f), sweeps, bad) == 0) then
+        if (bad > 0) print *, "Warning: IOPT_NMAXEX exceeded. Coarse-mesh solution may not have converged"
+      end if
+      call mg_destroy(s2(f)); live2(f) = .false.
     end do
 
     ! ---- 3. A_t = -grad(chi) x n --------------------------------------
@@ -235,7 +245,9 @@ contains
     end do
 
 900 continue
-    if (live2) call mg_destroy(s2)
+    do f = 1, 6
+      if (live2(f)) call mg_destroy(s2(f))
+    end do
 
   contains
 
