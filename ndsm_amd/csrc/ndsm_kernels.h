@@ -77,6 +77,7 @@ int ndsmk_device_count(void);
 int ndsmk_init(int device);                 /* device < 0: LOCAL_RANK % count (else 0) */
 int ndsmk_shutdown(void);
 const char *ndsmk_last_error(void);
+int ndsmk_note_error(int code, const char *what);   /* records the text, returns code */
 int ndsmk_device_name(char *buf, int len);
 void *ndsmk_stream(void);                   /* the library's hipStream_t */
 

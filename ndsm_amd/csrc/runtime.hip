@@ -228,6 +228,14 @@ extern "C" {
 
 const char *ndsmk_last_error(void) { return g_rt.err; }
 
+// host-side argument errors of the Fortran layer: leave their text where ndsmk_last_error finds it
+int ndsmk_note_error(int code, const char *what) {
+  std::snprintf(g_rt.err, sizeof(g_rt.err), "%s (code %d)", what ? what : "error", code);
+  if (const char *v = std::getenv("NDSM_HIP_VERBOSE"))
+    if (v[0] == '1') std::fprintf(stderr, "ERROR(libndsm_hip):%s\n", g_rt.err);
+  return code;
+}
+
 int ndsmk_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -175,6 +175,13 @@ module ndsmh_iface
       integer(c_int) :: ok
     end function
 
+    function ndsmk_note_error(code, what) bind(c, name="ndsmk_note_error") result(rc)
+      import :: c_int, c_char
+      integer(c_int), value :: code
+      character(kind=c_char), intent(in) :: what(*)
+      integer(c_int) :: rc
+    end function
+
     function ndsmk_select_lane(lane) bind(c, name="ndsmk_select_lane") result(rc)
       import :: c_int
       integer(c_int), value :: lane

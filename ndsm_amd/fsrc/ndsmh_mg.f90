@@ -114,11 +114,18 @@ contains
     integer(c_size_t) :: nbytes
 
     rc = NDSMK_EARG
-    if (ndim /= 2 .and. ndim /= 3) return
-    if (any(nshape(1:ndim) < 4)) return        ! the reference needs nmin >= 4 for one grid
+    if (ndim /= 2 .and. ndim /= 3) then
+      rc = ndsmk_note_error(NDSMK_EARG, "multigrid solver: 2 or 3 dimensions"//c_null_char); return
+    end if
+    if (any(nshape(1:ndim) < 4)) then          ! the reference needs nmin >= 4 for one grid (its level count
+      ! FLOOR(LOG(nmin / 4) / LOG(2)) + 1 is not positive below that and it stops or crashes)
+      rc = ndsmk_note_error(NDSMK_EARG, "grid too small: every dimension needs at least 4 points"//c_null_char); return
+    end if
     if (size(bcs) < 2 * ndim) return
     do d = 1, 2 * ndim
-      if (bcs(d) /= 'D' .and. bcs(d) /= 'N') return
+      if (bcs(d) /= 'D' .and. bcs(d) /= 'N') then
+        rc = ndsmk_note_error(NDSMK_EARG, "boundary letters must be D or N"//c_null_char); return
+      end if
     end do
 
     s%ndim = ndim

@@ -315,6 +315,31 @@ def test_pipeline_known_answer_rows(hip, n, mean):
     assert got == (RESULTS_TEST2 if mean else RESULTS_TEST1)[n]
 
 
+@pytest.mark.parametrize("ns", ([4, 4, 4], [4, 5, 7], [6, 4, 9], [7, 7, 4]), ids=_tag)
+def test_pipeline_smallest_grids(hip, port, ns):
+    """the smallest grids the reference's algorithm is defined on (every dimension >= 4: one or two levels, 2-D
+    faces of 4 x 4 points) against the oracle, at the pipeline's stated tolerance"""
+    import ndsm_amd
+    x, y, z, _A1, b = analytic_case(ns)
+    ierr, A, B = ndsm_amd.vector_potential(x, y, z, b.copy())
+    ierr2, A2, B2, _io, _ro = port.vector_potential(x, y, z, b)
+    assert ierr == ierr2
+    sc = np.abs(A2).max()
+    h = x[1] - x[0]
+    assert np.abs(A - A2).max() <= 1e-11 * sc and np.abs(B - B2).max() <= 1e-11 * sc * 4 / h
+
+
+@pytest.mark.parametrize("ns", ([3, 8, 8], [2, 9, 9], [2, 2, 2]), ids=_tag)
+def test_pipeline_grid_too_small_is_an_error_code(hip, ns):
+    """below four points in a dimension the reference's level count FLOOR(LOG(nmin/4)/LOG(2)) + 1 is not positive
+    and the reference itself stops or crashes (seen with oracle/_ref); here: return code 9002, A untouched, a text"""
+    import ndsm_amd
+    x, y, z, _A1, b = analytic_case(ns)
+    ierr, A, _B = ndsm_amd.vector_potential(x, y, z, b.copy())
+    assert ierr == 9002 and not A.any()
+    assert "at least 4 points" in hip.last_error(hip.load_library())
+
+
 def test_2d_neumann_solve_error_scaling(hip):
     """the reference's unit_test_2D_solve property (tests/unit_tests/unit_test_2D_solve.f90:63-242; stale there -
     it no longer compiles - so re-stated, not run): the 2-D all-Neumann Poisson problem laplace(u) = a (2x - Lx)
