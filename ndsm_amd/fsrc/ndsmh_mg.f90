@@ -81,7 +81,8 @@ module ndsmh_mg
     ! ---- one V-cycle + metric as an executable graph (mg_solve_lanes; small solves that are launch bound) ----
     type(c_ptr) :: graph = c_null_ptr    ! hipGraphExec_t, or null
     type(c_ptr) :: gkey_p(3) = c_null_ptr  ! what it was recorded for: level-1 u, rhs, prev ...
-    integer :: gkey_i(5) = 0             ! ... ms, nmax_exact, use_max, first level of the tail launch, lane (its scratch)
+    integer :: gkey_i(6) = 0             ! ... ms, nmax_exact, use_max, first level of the tail launch, lane (its
+                                         ! scratch), level-1 rhs declared zero
     real(wp) :: gkey_r = 0               ! ... ex_tol
     integer :: precision = 0             ! 0 fp64 (reference arithmetic), 1 mixed where level 1 is large enough,
                                          ! 2 mixed wherever the fp32 kernels cover level 1 (tests)
@@ -370,14 +371,14 @@ contains
     ok = c_associated(s%gkey_p(1), s%dl(1)%u) .and. c_associated(s%gkey_p(2), s%dl(1)%rhs) .and. &
          c_associated(s%gkey_p(3), s%prev) .and. s%gkey_i(1) == s%ms .and. s%gkey_i(2) == s%nmax_exact .and. &
          s%gkey_i(3) == merge(1, 0, s%use_max) .and. s%gkey_i(4) == tail_first(s, 1) .and. s%gkey_i(5) == lane .and. &
-         s%gkey_r == s%ex_tol
+         s%gkey_i(6) == merge(1, 0, s%rhs1_zero) .and. s%gkey_r == s%ex_tol
   end function
 
   subroutine graph_stamp(s, lane)
     type(mg_solver), intent(inout) :: s
     integer, intent(in) :: lane
     s%gkey_p = [s%dl(1)%u, s%dl(1)%rhs, s%prev]
-    s%gkey_i = [s%ms, s%nmax_exact, merge(1, 0, s%use_max), tail_first(s, 1), lane]
+    s%gkey_i = [s%ms, s%nmax_exact, merge(1, 0, s%use_max), tail_first(s, 1), lane, merge(1, 0, s%rhs1_zero)]
     s%gkey_r = s%ex_tol
   end subroutine
 
