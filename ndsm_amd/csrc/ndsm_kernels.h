@@ -178,6 +178,8 @@ int ndsmk_balance_curl_slab(double *A, double *B, const int32_t *n3, int kg0, in
 int ndsmk_balance_component(double *Ac, const int32_t *n3, int c, const double *x, const double *y, const double *z,
                             const double *h_phi6, const double *h_span3);
 int ndsmk_curl(const double *A, double *B, const int32_t *n3, const double *h_dq3);
+/* component c of B alone (needs the other two components of A only) */
+int ndsmk_curl_component(const double *A, double *B, const int32_t *n3, const double *h_dq3, int c);
 
 /* the face phase on the device (faces.hip): packed face buffers, six faces back to back */
 int ndsmk_face_offsets(const int32_t *n3, int64_t *off6, int64_t *total);

@@ -130,6 +130,33 @@ __global__ __launch_bounds__(256) void curl_k(const double *__restrict__ A, doub
   B[cb + 2 * NB] = ayx - axy;
 }
 
+// one component of the curl (same differences, same expressions as curl_k): component C of B needs only the
+// OTHER two components of A, so B_z can be formed - and go home - while A_z is still being solved
+template <int C>
+__global__ __launch_bounds__(256) void curl_comp_k(const double *__restrict__ A, double *__restrict__ B, PostArgs p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= p.n[0] || j >= p.n[1]) return;
+  const size_t sy = (size_t)p.n[0], sz = (size_t)p.n[0] * p.n[1];
+  const size_t N = sz * p.na;
+  const size_t c = (size_t)i + sy * (size_t)j + sz * (size_t)k;
+  const double *Ax = A, *Ay = A + N, *Az = A + 2 * N;
+  if (C == 0) {
+    const double ayz = ddq(Ay, c, k, p.n[2], sz, p.dq[2]);
+    const double azy = ddq(Az, c, j, p.n[1], sy, p.dq[1]);
+    B[c] = azy - ayz;          // :802
+  } else if (C == 1) {
+    const double axz = ddq(Ax, c, k, p.n[2], sz, p.dq[2]);
+    const double azx = ddq(Az, c, i, p.n[0], 1, p.dq[0]);
+    B[c + N] = axz - azx;      // :803
+  } else {
+    const double axy = ddq(Ax, c, j, p.n[1], sy, p.dq[1]);
+    const double ayx = ddq(Ay, c, i, p.n[0], 1, p.dq[0]);
+    B[c + 2 * N] = ayx - axy;  // :804
+  }
+}
+
 }  // namespace
 
 // A: device array (nx,ny,na,3) holding global planes [kg0, kg0 + na); B: (nx,ny,nb,3), its plane 0
@@ -228,6 +255,33 @@ extern "C" int ndsmk_curl(const double *A, double *B, const int32_t *n3, const d
   dim3 block(64, 4, 1);
   dim3 grid((n3[0] + 63) / 64, (n3[1] + 3) / 4, n3[2]);
   hipLaunchKernelGGL(curl_k, grid, block, 0, ndsm::stream(), A, B, p);
+  NDSM_LAUNCH_CHECK();
+  return 0;
+}
+
+// component c (0, 1, 2) of B = curl A alone, whole field: reads the other two components of A only
+extern "C" int ndsmk_curl_component(const double *A, double *B, const int32_t *n3, const double *h_dq3, int c) {
+  NDSM_REQUIRE_READY();
+  NDSM_CHECK_ARG(A && B && n3[0] >= 3 && n3[1] >= 3 && n3[2] >= 3 && c >= 0 && c < 3);
+  PostArgs p;
+  p.kg0 = 0;
+  p.na = p.nb = n3[2];
+  p.boff = 0;
+  for (int d = 0; d < 3; ++d) {
+    p.n[d] = n3[d];
+    p.span[d] = 0.0;
+    p.dq[d] = h_dq3[d];
+  }
+  for (int f = 0; f < 6; ++f) p.phi[f] = 0.0;
+  p.x = p.y = p.z = nullptr;
+  dim3 block(64, 4, 1);
+  dim3 grid((n3[0] + 63) / 64, (n3[1] + 3) / 4, n3[2]);
+  if (c == 0)
+    hipLaunchKernelGGL(curl_comp_k<0>, grid, block, 0, ndsm::stream(), A, B, p);
+  else if (c == 1)
+    hipLaunchKernelGGL(curl_comp_k<1>, grid, block, 0, ndsm::stream(), A, B, p);
+  else
+    hipLaunchKernelGGL(curl_comp_k<2>, grid, block, 0, ndsm::stream(), A, B, p);
   NDSM_LAUNCH_CHECK();
   return 0;
 }

@@ -461,6 +461,15 @@ module ndsmh_iface
       real(c_double), intent(in) :: phi6(6), span3(3)
       integer(c_int) :: rc
     end function
+    function ndsmk_curl_component(A, B, n3, dq3, c) bind(c, name="ndsmk_curl_component") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: A, B
+      integer(c_int32_t), intent(in) :: n3(3)
+      real(c_double), intent(in) :: dq3(3)
+      integer(c_int), value :: c
+      integer(c_int) :: rc
+    end function
+
     function ndsmk_curl(A, B, n3, dq3) bind(c, name="ndsmk_curl") result(rc)
       import :: c_ptr, c_int, c_int32_t, c_double
       type(c_ptr), value :: A, B

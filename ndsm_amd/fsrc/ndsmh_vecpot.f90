@@ -434,7 +434,7 @@ contains
     character(len=8) :: envbuf
     integer(ik) :: sweeps, bad, npts, cnt
     integer(c_int) :: tick_up(3), tick, zero_flag, rcb
-    logical :: use_max, resident, host_faces, late_balance
+    logical :: use_max, resident, host_faces, late_balance, bz_done
     character(len=1) :: bc3(6)
     type(c_ptr) :: dAout, dBout, u3, rhs2, u2
     integer(c_size_t) :: nb, off_y, off_z, fr, tot
@@ -453,6 +453,7 @@ contains
     off_y = int(n3(1), c_size_t) * 8_c_size_t
     off_z = off_y + int(n3(2), c_size_t) * 8_c_size_t
     late_balance = (iopt(IOPT_FLXCRL) == 1)     ! :455-465: curl first, fields added to A AND B afterwards
+    bz_done = .false.
     call get_environment_variable("NDSM_HIP_HOST_FACES", status=st)   ! A/B testing: the host face phase (vecpot_faces)
     host_faces = (st == 0) .and. .not. on_device
     tick_up = -1
@@ -624,6 +625,17 @@ contains
             rc = ndsmk_bg_download(c_loc(hA(1, 1, 1, c)), dptr_offset(dAout, int(c - 1, c_size_t) * nb), nb, tick)
             if (rc /= 0) goto 900
           end if
+          ! B_z = d(A_y)/dx - d(A_x)/dy needs the two components that are final now: it is formed here and goes
+          ! home behind the A_z solve as well (when B's device array exists already: not on the lean path)
+          call get_environment_variable("NDSM_HIP_NO_EARLY_BZ", status=st)      ! A/B testing: one curl at the end
+          if (c == 2 .and. c_associated(dBout) .and. all(n3 >= 3) .and. st /= 0) then
+            rc = ndsmk_curl_component(dAout, dBout, n3, dq, 2_c_int); if (rc /= 0) goto 900
+            if (.not. on_device) then
+              rc = ndsmk_bg_download(c_loc(hB(1, 1, 1, 3)), dptr_offset(dBout, 2_c_size_t * nb), nb, tick)
+              if (rc /= 0) goto 900
+            end if
+            bz_done = .true.
+          end if
         end if
       end do
     end associate
@@ -643,11 +655,14 @@ contains
       if (.not. on_device) then
         rc = ndsmk_bg_download(pA, dAout, 3_c_size_t * nb, tick); if (rc /= 0) goto 900
       end if
+    else if (bz_done) then
+      rc = ndsmk_curl_component(dAout, dBout, n3, dq, 0_c_int); if (rc /= 0) goto 900
+      rc = ndsmk_curl_component(dAout, dBout, n3, dq, 1_c_int); if (rc /= 0) goto 900
     else
       rc = ndsmk_curl(dAout, dBout, n3, dq); if (rc /= 0) goto 900
     end if
     if (.not. on_device) then
-      rc = ndsmk_bg_download(pB, dBout, 3_c_size_t * nb, tick); if (rc /= 0) goto 900
+      rc = ndsmk_bg_download(pB, dBout, merge(2_c_size_t, 3_c_size_t, bz_done) * nb, tick); if (rc /= 0) goto 900
     end if
     iopt(IOPT_IERR) = ierr2d                                ! Q3'
     call say(me, "Deallocate memory...")

@@ -315,6 +315,28 @@ def test_pipeline_known_answer_rows(hip, n, mean):
     assert got == (RESULTS_TEST2 if mean else RESULTS_TEST1)[n]
 
 
+def test_bz_formed_behind_the_az_solve_bitwise(hip):
+    """B_z = d(A_y)/dx - d(A_x)/dy is formed (and sent home) as soon as A_x and A_y are final, behind the A_z solve;
+    against the single curl at the end (NDSM_HIP_NO_EARLY_BZ=1): the same A and B, bit for bit - on a field whose
+    three components all take several cycles, odd and even shapes"""
+    import ndsm_amd
+    keep = os.environ.get("NDSM_HIP_NO_EARLY_BZ")
+    try:
+        for ns in ([96, 80, 72], [33, 22, 27]):
+            x, y, z, _A1, b = analytic_case(ns)
+            b = b + 0.2 * np.random.default_rng(4).standard_normal(b.shape)
+            os.environ.pop("NDSM_HIP_NO_EARLY_BZ", None)
+            i1, A, B = ndsm_amd.vector_potential(x, y, z, b)
+            os.environ["NDSM_HIP_NO_EARLY_BZ"] = "1"
+            i2, A2, B2 = ndsm_amd.vector_potential(x, y, z, b)
+            assert i1 == i2 and np.array_equal(A, A2) and np.array_equal(B, B2), ns
+    finally:
+        if keep is None:
+            os.environ.pop("NDSM_HIP_NO_EARLY_BZ", None)
+        else:
+            os.environ["NDSM_HIP_NO_EARLY_BZ"] = keep
+
+
 @pytest.mark.parametrize("ns", ([4, 4, 4], [4, 5, 7], [6, 4, 9], [7, 7, 4]), ids=_tag)
 def test_pipeline_smallest_grids(hip, port, ns):
     """the smallest grids the reference's algorithm is defined on (every dimension >= 4: one or two levels, 2-D
