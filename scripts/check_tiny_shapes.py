@@ -1,3 +1,5 @@
+"""tiny grids: ours against the oracle port where the reference's algorithm is defined (every dimension >= 4); below
+that the reference itself dies (negative level count -> STOP / crash), this library returns an error code (dev aid)"""
 import os, sys
 ROOT = "/root/repo"
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -6,8 +8,6 @@ import ndsm_amd
 from oracle import Oracle
 from golden_inputs import analytic_case
 port = Oracle("port")
-"""tiny grids: ours against the oracle port where the reference's algorithm is defined (every dimension >= 4); below
-that the reference itself dies (negative level count -> STOP / crash), this library returns an error code (dev aid)"""
 for ns in ([4,4,4],[4,5,7],[5,5,5],[6,4,9],[7,7,4],[3,8,8],[2,9,9],[3,3,3],[2,2,2]):
     try:
         x, y, z, A1, b = analytic_case(ns)
