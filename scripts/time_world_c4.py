@@ -1,3 +1,4 @@
+"""BASELINE config[3] (1024 x 1024 x 512): solve-loop cycle of the single-domain solver and of the 8-slab loop-back world, Laplace or (argument `rhs`) manufactured Poisson problem (dev aid)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, ndsm_amd
