@@ -16,6 +16,8 @@
 // six to three.
 #include "common.hpp"
 
+#include <type_traits>
+
 #include <cstdlib>
 
 namespace {
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(CI *CJ) void restrict_stream_k(const TF *__restrict
 //     coarse point one column earlier than in the reference.)
 // Same tap order and weight chain: bit-identical (tests/test_gpu_parity.py::test_transfer3d_bitwise,
 // test_large_level_kernels_bitwise, the V-cycle tests).
-template <typename TF, int CI, int CJ, int MT, int KCMAX, int WPS, bool ODDX, int DEPTH = 3>
+template <typename TF, int CI, int CJ, int MT, int KCMAX, int WPS, bool ODDX, int DEPTH = 3, bool ROWB = false, bool SCHED = false>
 __global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__restrict__ f, double *__restrict__ rhs_c,
                                                                   double *__restrict__ u_c, RSArgs a) {
   constexpr int NT = CI * CJ;
@@ -401,9 +403,78 @@ __global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__re
   };
 
   // the taps of fine plane k (in LDS buffer R) for every coarse plane whose z window holds it
-  auto consume = [&](int k, const double *R) {
+  // the taps of one fine plane for two coarse planes at once (they share the plane's values and the x-y weight
+  // prefixes) / for one
+  auto taps2 = [&](const double *P, double c2za, double c2zb, double &fa, double &fb) {
+    if constexpr (ROWB) {
+      // a row's taps behind ONE wait: inside each branch the x tap count is a compile-time constant (the wave's
+      // 3, 4 or 5), so a row is NI LDS reads issued back to back and then its multiply / add chain - with a
+      // uniform branch around every tap each read was waited for on its own (139 s_waitcnt per plane-step)
+      auto rows = [&](auto ni_c) {
+        constexpr int NI = decltype(ni_c)::value;
+#pragma unroll
+        for (int jj = 0; jj < MT; ++jj) {
+          if (jj < njw) {
+            double fv[NI];
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii) fv[ii] = P[ii + FX * jj];
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii) {
+              const double w0 = cxw[ii] * cy[jj] * a.w2[1];
+              const double wa = w0 * c2za * a.w2[2];
+              const double wb = w0 * c2zb * a.w2[2];
+              fa = fa + wa * fv[ii];
+              fb = fb + wb * fv[ii];
+            }
+          }
+        }
+      };
+      if (nim == 4)
+        rows(std::integral_constant<int, 4>());
+      else if (nim == 5)
+        rows(std::integral_constant<int, 5>());
+      else
+        rows(std::integral_constant<int, 3>());   // (fewer: the weights of the taps a column lacks are zero)
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < MT; ++jj) {
+        if (jj < njw) {
+#pragma unroll
+          for (int ii = 0; ii < MT; ++ii) {
+            if (ii < nim) {
+              const double w0 = cxw[ii] * cy[jj] * a.w2[1];
+              const double wa = w0 * c2za * a.w2[2];
+              const double wb = w0 * c2zb * a.w2[2];
+              const double fv = P[ii + FX * jj];
+              fa = fa + wa * fv;
+              fb = fb + wb * fv;
+            }
+          }
+        }
+      }
+    }
+  };
+  auto taps1 = [&](const double *P, double c2za, double &fa) {
+#pragma unroll
+    for (int jj = 0; jj < MT; ++jj) {
+      if (jj < njw) {
+#pragma unroll
+        for (int ii = 0; ii < MT; ++ii) {
+          if (ii < nim) {
+            const double w0 = cxw[ii] * cy[jj] * a.w2[1];
+            const double wa = w0 * c2za * a.w2[2];
+            fa = fa + wa * P[ii + FX * jj];
+          }
+        }
+      }
+    }
+  };
+
+  // the taps of fine plane k (in LDS buffer R) for every coarse plane K >= Kfrom whose z window holds it: the
+  // windows are looked up in the chunk's z tables as the walk goes
+  auto consume_from = [&](int k, const double *R, int Kfrom) {
     const double *P = R + li0 + FX * lj0;
-    int K = Klo;
+    int K = Kfrom;
     while (K < Ke) {
       const int z0 = __builtin_amdgcn_readfirstlane(s_z0[K - Ks]);
       if (z0 > k) break;
@@ -424,61 +495,111 @@ __global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__re
       if (two) {
         const double c2zb = s_zw[(K + 1 - Ks) * MT + (k - z1)];
         double fb = getacc((K + 1) & 3);
-#pragma unroll
-        for (int jj = 0; jj < MT; ++jj) {
-          if (jj < njw) {
-#pragma unroll
-            for (int ii = 0; ii < MT; ++ii) {
-              if (ii < nim) {
-                const double w0 = cxw[ii] * cy[jj] * a.w2[1];
-                const double wa = w0 * c2za * a.w2[2];
-                const double wb = w0 * c2zb * a.w2[2];
-                const double fv = P[ii + FX * jj];
-                fa = fa + wa * fv;
-                fb = fb + wb * fv;
-              }
-            }
-          }
-        }
+        taps2(P, c2za, c2zb, fa, fb);
         finish(K, fa, k == z0 + nk - 1);
         finish(K + 1, fb, k == z1 + nk1 - 1);
         K += 2;
       } else {
-#pragma unroll
-        for (int jj = 0; jj < MT; ++jj) {
-          if (jj < njw) {
-#pragma unroll
-            for (int ii = 0; ii < MT; ++ii) {
-              if (ii < nim) {
-                const double w0 = cxw[ii] * cy[jj] * a.w2[1];
-                const double wa = w0 * c2za * a.w2[2];
-                fa = fa + wa * P[ii + FX * jj];
-              }
-            }
-          }
-        }
+        taps1(P, c2za, fa);
         finish(K, fa, k == z0 + nk - 1);
         K += 1;
       }
     }
+  };
+  auto consume = [&](int k, const double *R) {
+    consume_from(k, R, Klo);
     while (Klo < Ke && __builtin_amdgcn_readfirstlane(s_z0[Klo - Ks] + s_nk[Klo - Ks]) - 1 <= k) ++Klo;
+  };
+
+  // SCHED: that walk costs three to five dependent LDS round trips (window starts, lengths, weights, each read
+  // made wave-uniform with a readfirstlane) before the first multiplication of every plane-step.  The answers do
+  // not depend on the data: a schedule per fine plane of the chunk - first coarse plane that takes it, how many do
+  // (up to 4 recorded; any further ones are walked), their z weights, which of them it completes - is built once
+  // from the z tables, and the record of plane k+1 is read while plane k's step drains into its barrier.
+  constexpr int KPL = SCHED ? 2 * KCMAX + 16 : 1;
+  __shared__ int s_sk[KPL], s_sc[KPL];
+  __shared__ double s_sw[4 * KPL];
+  const int nrec = SCHED ? min(kB - kA + 1, KPL) : 0;
+  int rk = 0, rc = 0;
+  double rw0 = 0.0, rw1 = 0.0, rw2 = 0.0, rw3 = 0.0;
+  auto read_rec = [&](int k) {
+    const int t = min(k - kA, nrec - 1);
+    rk = s_sk[t];
+    rc = k - kA < nrec ? s_sc[t] : 0;
+    rw0 = s_sw[4 * t];
+    rw1 = s_sw[4 * t + 1];
+    rw2 = s_sw[4 * t + 2];
+    rw3 = s_sw[4 * t + 3];
+  };
+  // (the host only selects this form where a chunk has at most KPL fine planes and no fine plane lies in more
+  // than four coarse windows: ndsmh_mg.f90:stream_restrict_applies)
+  auto consume_s = [&](const double *R) {
+    const int cc = __builtin_amdgcn_readfirstlane(rc);
+    const int cnt = cc & 255, done = cc >> 8;
+    const double *P = R + li0 + FX * lj0;
+    const int K0 = __builtin_amdgcn_readfirstlane(rk);
+    int e = 0;
+    while (e < cnt) {          // one or two rounds: pairs of coarse planes, then a single one
+      const int K = K0 + e;
+      const double wa = e == 0 ? rw0 : rw2;
+      double fa = getacc(K & 3);
+      if (cnt - e >= 2) {
+        const double wb = e == 0 ? rw1 : rw3;
+        double fb = getacc((K + 1) & 3);
+        taps2(P, wa, wb, fa, fb);
+        finish(K, fa, ((done >> e) & 1) != 0);
+        finish(K + 1, fb, ((done >> (e + 1)) & 1) != 0);
+        e += 2;
+      } else {
+        taps1(P, wa, fa);
+        finish(K, fa, ((done >> e) & 1) != 0);
+        e += 1;
+      }
+    }
   };
 
   // ---- prologue: plane kA into LDS buffer 0, planes kA+1 (, kA+2) on their way ----
   static_assert(DEPTH == 2 || DEPTH == 3, "planes in flight");
   d2 r0[NS], r1[NS], r2[DEPTH == 3 ? NS : 1];
-  __syncthreads();  // the zero fill is complete
+  __syncthreads();  // the zero fill is complete (and the z tables are)
   load_plane(kA, r0);
   load_plane(kA + 1, r1);
   if constexpr (DEPTH == 3) load_plane(kA + 2, r2);
+  if constexpr (SCHED) {
+    for (int t = tid; t < nrec; t += NT) {
+      const int k = kA + t;
+      int K0 = Ke, c = 0, done = 0;
+      for (int K = Ks; K < Ke; ++K) {
+        const int z0 = s_z0[K - Ks], nk = s_nk[K - Ks];
+        if (k >= z0 && k < z0 + nk) {
+          if (c == 0) K0 = K;
+          if (c < 4) {
+            s_sw[4 * t + c] = s_zw[(K - Ks) * MT + (k - z0)];
+            if (k == z0 + nk - 1) done |= 1 << c;
+          }
+          ++c;
+        }
+      }
+      for (int q = c; q < 4; ++q) s_sw[4 * t + q] = 0.0;
+      s_sk[t] = K0;
+      s_sc[t] = (c > 255 ? 255 : c) | (done << 8);
+    }
+  }
   store_plane(lds, r0, true);
-  __syncthreads();  // also publishes the z tables
+  __syncthreads();  // also publishes the schedule
+  if constexpr (SCHED) read_rec(kA);
 
   // one plane-step: request plane k+DEPTH into the slot plane k came from, consume plane k, move plane k+1
   // from its slot into the other LDS buffer
   auto step = [&](int k, d2(&slot_k)[NS], const d2(&slot_k1)[NS]) {
     if (a.probe != 2) load_plane(k + DEPTH, slot_k);
-    if (a.probe != 1) consume(k, lds + ((k - kA) & 1) * PLANE);
+    if constexpr (SCHED) {
+      if (a.probe != 1) consume_s(lds + ((k - kA) & 1) * PLANE);
+      read_rec(k + 1);   // (its LDS reads ride the barrier below)
+    } else {
+      if (a.probe != 1) consume(k, lds + ((k - kA) & 1) * PLANE);
+    }
+    (void)consume;
     store_plane(lds + ((k + 1 - kA) & 1) * PLANE, slot_k1, k + 1 <= kB);
     __syncthreads();
   };
@@ -500,8 +621,14 @@ constexpr int kCI = 64, kMT = 5, kKCMax = 64;
 
 // which form of the kernel runs (NDSM_RS_VARIANT; tuning aid): 0 the first kernel (64 x 8 coarse columns,
 // one plane of prefetch: 432 us at 512^3), 1 restrict_stream2_k with 64 x 8 columns and three planes in flight
-// (388-393 us, the default); with two planes in flight: 2 = 64 x 4 columns (256 threads: twice as many independent
-// barrier groups per CU; 391 us), 5 = 64 x 8 columns (383 us).  Forcing three workgroups per CU (<= 85 VGPRs)
+// (388-393 us, the default until the end of round 2); with two planes in flight: 2 = 64 x 4 columns (256 threads:
+// twice as many independent barrier groups per CU; 391 us), 5 = 64 x 8 columns (383 us).
+// 8 (the default now) = 5 + the per-chunk SCHEDULE of the z windows (SCHED: see consume_s) - the walk through the
+// window tables cost three to five dependent LDS round trips and as many scalar instructions as the plane-step
+// has vector ones (counters: 8.8e7 SALU against 1.1e8 VALU instructions); with the record of the next plane read
+// behind the barrier: 361-373 us on the box where 1 takes 397-402 (arithmetic alone 334 against 373).
+// 6 / 7 / 9 = the x taps of a row read back to back behind one wait (ROWB) on top of 5 / 1 / 8: 383-391 us for 6
+// (the per-tap waits were not the limit), 7 and 9 spill (528 / 466 us).  Forcing three workgroups per CU (<= 85 VGPRs)
 // spills and takes 816-1400 us: not built.  Neither the prefetch depth nor the number of barrier groups moves
 // the kernel any further, because it is bound by the tap arithmetic, not by memory: with the arithmetic skipped
 // the same launch streams its 1.28 GB in 174-190 us (6.7-7.3 TB/s), with the loads skipped the arithmetic alone
@@ -514,8 +641,8 @@ int rs_variant() {
   static int variant = -1;
   if (variant < 0) {
     const char *e = std::getenv("NDSM_RS_VARIANT");
-    variant = e ? std::atoi(e) : 1;
-    if (variant != 0 && variant != 2 && variant != 5) variant = 1;
+    variant = e ? std::atoi(e) : 8;
+    if (variant != 0 && variant != 1 && variant != 2 && (variant < 5 || variant > 9)) variant = 8;
   }
   return variant;
 }
@@ -534,7 +661,7 @@ extern "C" void ndsmk_restrict_stream_tile(int *ci, int *cj, int *fx, int *fy, i
   *maxt = kMT;
 }
 
-template <typename TF, int CJ, int WPS, bool OLD, int DEPTH = 3>
+template <typename TF, int CJ, int WPS, bool OLD, int DEPTH = 3, bool ROWB = false, bool SCHED = false>
 static int launch_rs_v(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double *u_c) {
   RSArgs a;
   for (int d = 0; d < 3; ++d) {
@@ -560,8 +687,8 @@ static int launch_rs_v(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
   if constexpr (OLD) {
     kfn = reinterpret_cast<const void *>(restrict_stream_k<TF, kCI, CJ, kMT, kKCMax>);
   } else {
-    kfn = odd ? reinterpret_cast<const void *>(restrict_stream2_k<TF, kCI, CJ, kMT, kKCMax, WPS, true, DEPTH>)
-              : reinterpret_cast<const void *>(restrict_stream2_k<TF, kCI, CJ, kMT, kKCMax, WPS, false, DEPTH>);
+    kfn = odd ? reinterpret_cast<const void *>(restrict_stream2_k<TF, kCI, CJ, kMT, kKCMax, WPS, true, DEPTH, ROWB, SCHED>)
+              : reinterpret_cast<const void *>(restrict_stream2_k<TF, kCI, CJ, kMT, kKCMax, WPS, false, DEPTH, ROWB, SCHED>);
   }
   // coarse planes per chunk: a chunk of kc coarse planes walks ~2 kc + 3 fine planes: minimise (rounds of
   // workgroups at the kernel's occupancy) x (planes walked); the chunk's z tables must fit their LDS
@@ -602,10 +729,16 @@ static int launch_rs_v(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
 
 template <typename TF>
 static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double *u_c) {
-  switch (rs_variant()) {
+  int v = rs_variant();
+  if ((v == 8 || v == 9) && !(x->stream_ok & 4)) v = 5;   // the scheduled forms need the host's word on the z windows
+  switch (v) {
     case 0: return launch_rs_v<TF, 8, 4, true>(x, r_f, rhs_c, u_c);
     case 2: return launch_rs_v<TF, 4, 4, false, 2>(x, r_f, rhs_c, u_c);
     case 5: return launch_rs_v<TF, 8, 4, false, 2>(x, r_f, rhs_c, u_c);
+    case 6: return launch_rs_v<TF, 8, 4, false, 2, true>(x, r_f, rhs_c, u_c);
+    case 7: return launch_rs_v<TF, 8, 4, false, 3, true>(x, r_f, rhs_c, u_c);
+    case 9: return launch_rs_v<TF, 8, 4, false, 2, true, true>(x, r_f, rhs_c, u_c);
+    case 8: return launch_rs_v<TF, 8, 4, false, 2, false, true>(x, r_f, rhs_c, u_c);
     default: return launch_rs_v<TF, 8, 4, false>(x, r_f, rhs_c, u_c);
   }
 }

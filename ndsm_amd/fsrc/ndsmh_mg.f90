@@ -294,6 +294,29 @@ contains
     end do
     ok = 2
     if (s%lev(l)%npts >= 6_ik * 1024_ik * 1024_ik) ok = 3
+    ! bit 2: the kernel's per-chunk schedule holds this pair's z windows - no fine plane lies in more than four
+    ! coarse windows, and 64 consecutive coarse planes (the longest chunk) span at most 144 fine planes
+    block
+      integer :: cntf(0:t(3)%nf), kk
+      logical :: sched
+      cntf = 0
+      do k = 1, t(3)%nc
+        cntf(t(3)%rlo(k)) = cntf(t(3)%rlo(k)) + 1
+        kk = t(3)%rlo(k) + t(3)%rcnt(k)
+        if (kk <= t(3)%nf) cntf(kk) = cntf(kk) - 1
+      end do
+      sched = .true.
+      kk = 0
+      do k = 0, t(3)%nf - 1
+        kk = kk + cntf(k)
+        if (kk > 4) sched = .false.
+      end do
+      do k = 1, t(3)%nc
+        a1 = min(k + 63, int(t(3)%nc))
+        if (t(3)%rlo(a1) + t(3)%rcnt(a1) - t(3)%rlo(k) > 144) sched = .false.
+      end do
+      if (sched) ok = ok + 4
+    end block
   end function
 
   ! Does resrest.hip cover the transfer l -> l+1?  3-D, even nx, a level large
