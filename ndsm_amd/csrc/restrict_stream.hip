@@ -630,7 +630,10 @@ constexpr int kCI = 64, kMT = 5, kKCMax = 64;
 // 6 / 7 / 9 = the x taps of a row read back to back behind one wait (ROWB) on top of 5 / 1 / 8: 383-391 us for 6
 // (the per-tap waits were not the limit), 7 and 9 spill (528 / 466 us).  Also tried on top of 8: accumulators kept
 // in completion order (entry e of the record = accumulator e, shifted down when planes complete: no selects on
-// a slot number) - the compiler parks three of the four accumulators in scratch and the launch takes 421 us.  Forcing three workgroups per CU (<= 85 VGPRs)
+// a slot number) - the compiler parks three of the four accumulators in scratch and the launch takes 421 us;
+// a parity-planar LDS plane (even fine columns first, then the odd ones: the tap reads of a wave become
+// consecutive words instead of every second one, no 2-way bank conflict) - same bits, 359-368 against 367-380 us:
+// inside the noise, as the counters said (LDS issue waits 0.7 % of the wave cycles); not kept.  Forcing three workgroups per CU (<= 85 VGPRs)
 // spills and takes 816-1400 us: not built.  Neither the prefetch depth nor the number of barrier groups moves
 // the kernel any further, because it is bound by the tap arithmetic, not by memory: with the arithmetic skipped
 // the same launch streams its 1.28 GB in 174-190 us (6.7-7.3 TB/s), with the loads skipped the arithmetic alone
