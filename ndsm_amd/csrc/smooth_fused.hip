@@ -48,8 +48,23 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace {
+
+// Plane loads and stores go through BUFFER instructions: one descriptor per plane
+// (scalar registers), a 32-bit byte offset per lane.  The range check stands in for every predicate - a lane
+// outside the domain (or not owned, for stores) carries an offset beyond the plane and a plane outside the
+// chunk gets a descriptor of zero records: such loads return 0 and such stores are dropped.  No load or store
+// sits under a branch, no 64-bit address arithmetic per lane.  (Round 3 also tried requesting planes TWO steps
+// ahead with counted waits, a spare LDS plane that removes one of the two barriers per step, and both together:
+// 0 to -4 % - the pass was never waiting for memory latency.  Result stores carry the non-temporal hint: +2 %.)
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+constexpr unsigned kDeadLane = 0x80000000u;   // >= any plane's byte count (launch_fused_t checks)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
 
 // MODE 3: tables of the interpolation from the next coarser level (ndsmk_xfer's prolongation half)
 struct ProlArgs {
@@ -87,43 +102,54 @@ struct Vec2<float> {
 };
 
 template <typename T>
-__device__ __forceinline__ P2<T> ld2(const T *p) {
-  const typename Vec2<T>::type t = *reinterpret_cast<const typename Vec2<T>::type *>(p);
-  P2<T> r;
-  r.x = t.x;
-  r.y = t.y;
-  return r;
+__device__ __forceinline__ P2<T> ldbuf(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  P2<T> v;
+  if constexpr (sizeof(T) == 8) {
+    const v4u_t a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    __builtin_memcpy(&v, &a, 16);
+  } else {
+    const v2u_t a = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    __builtin_memcpy(&v, &a, 8);
+  }
+  return v;
 }
-template <typename T>
-__device__ __forceinline__ void st2(T *p, const P2<T> &a) {
-  typename Vec2<T>::type t;
-  t.x = a.x;
-  t.y = a.y;
-  *reinterpret_cast<typename Vec2<T>::type *>(p) = t;
+template <typename T, int AUX>
+__device__ __forceinline__ void stbuf(__amdgpu_buffer_rsrc_t r, unsigned off, const P2<T> &v) {
+  if constexpr (sizeof(T) == 8) {
+    v4u_t a;
+    __builtin_memcpy(&a, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(a, r, off, 0, AUX);
+  } else {
+    v2u_t a;
+    __builtin_memcpy(&a, &v, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(a, r, off, 0, AUX);
+  }
 }
-// rows of an odd-nx level start at odd multiples of sizeof(T): same 16-byte (8-byte) access, but the
-// compiler must not assume natural alignment
+// ... and element by element: the rows of an odd-nx level are only sizeof(T)-aligned (a straddling 16-byte access
+// costs 1.35 x more), and the pair that holds the last column takes its second element from elsewhere (header)
 template <typename T>
-__device__ __forceinline__ P2<T> ld2u(const T *p) {
-  typedef T vec2 __attribute__((ext_vector_type(2)));
-  typedef vec2 vec2u __attribute__((aligned(sizeof(T))));
-  (void)sizeof(vec2u);
-  const T *p1 = p + 1;
-  asm volatile("" : "+v"(p1));   // two element-sized accesses: a straddling 16-byte one costs more
-  P2<T> r;
-  r.x = *p;
-  r.y = *p1;
-  return r;
+__device__ __forceinline__ T ldbuf1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  T v;
+  if constexpr (sizeof(T) == 8) {
+    const v2u_t a = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    __builtin_memcpy(&v, &a, 8);
+  } else {
+    const unsigned a = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+    __builtin_memcpy(&v, &a, 4);
+  }
+  return v;
 }
-template <typename T>
-__device__ __forceinline__ void st2u(T *p, const P2<T> &a) {
-  typedef T vec2 __attribute__((ext_vector_type(2)));
-  typedef vec2 vec2u __attribute__((aligned(sizeof(T))));
-  (void)sizeof(vec2u);
-  T *p1 = p + 1;
-  asm volatile("" : "+v"(p1));
-  *p = a.x;
-  *p1 = a.y;
+template <typename T, int AUX>
+__device__ __forceinline__ void stbuf1(__amdgpu_buffer_rsrc_t r, unsigned off, const T v) {
+  if constexpr (sizeof(T) == 8) {
+    v2u_t a;
+    __builtin_memcpy(&a, &v, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(a, r, off, 0, AUX);
+  } else {
+    unsigned a;
+    __builtin_memcpy(&a, &v, 4);
+    __builtin_amdgcn_raw_buffer_store_b32(a, r, off, 0, AUX);
+  }
 }
 // by value: selects on values, never on addresses
 template <typename T>
@@ -206,19 +232,25 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   constexpr bool DEFER = !RES;
   const T gw0 = (T)g.w[0], gw1 = (T)g.w[1], gw2 = (T)g.w[2], gw1i = (T)g.w1, gwc = (T)g.wc;
   constexpr int NST = 2 * S;                 // smoothing stages
-  constexpr int NSTG = RES ? NST + 1 : NST;  // pipeline depth = LDS planes = halo width
+  constexpr int NSTG = RES ? NST + 1 : NST;  // pipeline depth = halo width
+  constexpr int NB = NSTG;                   // LDS planes: one per pipeline stage
+  constexpr int STAUX = 2;                   // result stores: non-temporal (never re-read by this launch)
   constexpr int NPX = TXH / 2;
   constexpr int NPAIR = NPX * TYH;
   constexpr int NS = (NPAIR + NT - 1) / NT;
   constexpr int HX = (NSTG + 1) & ~1;        // x halo: even, pairs stay 16-byte aligned
   constexpr int TXI = TXH - 2 * HX, TYI = TYH - 2 * NSTG;
   constexpr int PLANE = TXH * TYH;
-  // An LDS plane is stored element-planar: first the element 0 of every pair, then every
-  // element 1.  A stage touches ONE element of each pair, so consecutive lanes then read
-  // consecutive words - with interleaved pairs every access had a 2-way bank conflict (42 % of
-  // the LDS cycles, SQ_LDS_BANK_CONFLICT).
-  constexpr int HALF = NPAIR * SZ;
-  constexpr int BIG = 1 << 20;
+  // LDS layout.  The points of a plane fall into two CLASSES by the parity of i + j (+ the slab / colour
+  // offsets): a pair holds one point of each, and in plane-step k every stage updates the class-(k & 1) point of
+  // every pair (colour and plane parity flip together).  The LDS keeps the classes apart - first the class-0
+  // points of all NB planes, then the class-1 points ("half-major") - so that WHICH half a stage reads and
+  // writes is the same for every lane and known per step: the updated point, its z neighbours and what the
+  // next stage needs of it sit in half k & 1, its four in-plane neighbours in the other half.  (Element e of a
+  // pair whose parity bit is par lies in half e ^ par.)  Consecutive lanes touch consecutive words: no bank
+  // conflicts - interleaved pairs had 2-way conflicts on every access (42 % of the LDS cycles).
+  constexpr int HALF = NPAIR * SZ;   // bytes of one class of one plane
+  constexpr int HSTR = NB * HALF;    // class h of the plane in buffer b starts at h * HSTR + b * HALF
   using SlotT = Slot<TXH, TYH, NT, HX, NSTG>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   T *const lds = reinterpret_cast<T *>(lds_raw);
@@ -247,50 +279,43 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   const int tid = tid0;
   const int fp = g.first_par & 1;
   // tile edges that coincide with the physical boundary do not shrink the valid region
-  const bool openxl = x0 > 0, openxh = x0 + TXH < nx, openyl = y0 > 0, openyh = y0 + TYH < ny;
-  // pair at offset go_ of a global plane: plain 16-byte access, or (ODD) an unaligned one and, for the
-  // pair that holds column nx-1 (flag bit 4), that column plus the ghost's source / nothing
-  auto ldpair = [&](const T *p, int fl_) {
-    if (ODD) {
-      d2 r;
-      if (fl_ & 16) {
-        r.x = p[0];
-        r.y = p[-1];
-      } else {
-        r = ld2u(p);
-      }
-      return r;
-    }
-    return ld2(p);
+  const bool openxh = x0 + TXH < nx, openyh = y0 + TYH < ny;
+  // descriptor of plane k of a field; ok == false: zero records (every load returns 0, every store is dropped)
+  const unsigned plane_bytes = (unsigned)(sz * (size_t)SZ);
+  auto rsrc_of = [&](const T *base, int k_, bool ok) {
+    return plane_rsrc(base + sz * (size_t)(ok ? k_ : 0), ok ? plane_bytes : 0u);
   };
-  auto stpair = [&](T *p, const d2 &v, int fl_) {
-    if (ODD) {
-      if (fl_ & 16)
-        p[0] = v.x;
-      else
-        st2u(p, v);
+  // a pair through descriptor r: o0 = byte offset of element 0; odd nx: o1 = that of element 1 (the ghost's source
+  // for loads, kDeadLane for its stores)
+  auto ldp = [&](__amdgpu_buffer_rsrc_t r, unsigned o0, unsigned o1) {
+    if constexpr (ODD) {
+      d2 v;
+      v.x = ldbuf1<T>(r, o0);
+      v.y = ldbuf1<T>(r, o1);
+      return v;
     } else {
-      st2(p, v);
+      return ldbuf<T>(r, o0);
+    }
+  };
+  auto stp = [&](__amdgpu_buffer_rsrc_t r, unsigned o0, unsigned o1, const d2 &v) {
+    if constexpr (ODD) {
+      stbuf1<T, STAUX>(r, o0, v.x);
+      stbuf1<T, STAUX>(r, o1, v.y);
+    } else {
+      stbuf<T, STAUX>(r, o0, v);
     }
   };
 
-#define NDSM_LOAD_PLANE(base, k, dst)                              \
-  do {                                                              \
-    const T *pk_ = (base) + sz * (size_t)(k);                  \
-    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {             \
-      const SlotT q_(tid, s_, x0, y0, nxs, ny);                     \
-      d2 t_;                                                        \
-      t_.x = 0.0;                                                   \
-      t_.y = 0.0;                                                   \
-      if (q_.in) t_ = ldpair(pk_ + (q_.i + nx * q_.j), (ODD && q_.i == nx - 1) ? 16 : 0); \
-      dst[s_] = t_;                                                 \
-    }                                                               \
+#define NDSM_LOAD_PLANE(base, k, dst)                                                                  \
+  do {                                                                                                  \
+    const auto r_ = plane_rsrc((base) + sz * (size_t)(k), plane_bytes);                                 \
+    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) dst[s_] = ldp(r_, scs[s_].ldo, scs[s_].ldo1);     \
   } while (0)
 
   // Register window per slot (everything else is re-read from LDS):
   //   nxt = plane k+1 (arrived), nn = plane k+2 (in flight)
-  //   mLe = the element of plane k-2S (final) the last stage needs as z-1 neighbour
-  //   rw[t] = rhs of plane k-t, rn = rhs of plane k+1 (in flight)
+  //   mLe = the point of plane k-2S (final) the last stage needs as z-1 neighbour
+  //   rw[t] = rhs of plane k-t IN CLASS ORDER (.x the class-0 point), rn = rhs of plane k+1 (in flight)
   d2 nxt[NS], nn[NS];
   //   RES: f1 / f2 = the final pairs of planes k-2S and k-2S-1
   d2 rw[RHS0 ? 1 : NS][RHS0 ? 1 : NSTG], rn[RHS0 ? 1 : NS];
@@ -316,78 +341,119 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     }
   }
 
-  // ---- per-slot constants of the z loop (byte offsets into an LDS plane) ----
-  // The loop body is issue bound, not bandwidth bound: everything that does not
-  // depend on k is computed once and kept in registers (NS <= 2 slots per thread).
+  // ---- per-slot constants of the z loop ----
+  // The pass is bound by INSTRUCTION ISSUE - a wave issues one instruction every four cycles whatever its kind -
+  // not by HBM, LDS bandwidth or the fp64 rate: round 2's plane-step spent ~70 instructions per point update, 9
+  // of them arithmetic, re-deriving per stage which LDS plane it works on, which element of the pair is its
+  // own and where that element's neighbours are.  None of that depends on k once the plane loop is unrolled
+  // over the LDS buffers (NCOPY copies of the step, below): buffer and class of every access are compile-time
+  // constants, every LDS address is one of the per-slot registers set up here plus an immediate offset, every
+  // per-lane predicate a lane mask in scalar registers.  Per update that leaves six LDS reads, nine flops
+  // and one masked write.
   struct SC {
-    int lo;        // the pair's slot in the first half of a plane (element 0); element 1 is HALF further
-    int yl, yh;    // signed row deltas to the y neighbours (mirrored at the physical faces; 0 where
-                   // the neighbour row is outside the tile - such rows are never updated)
-    int xlo, xhi;  // outer x neighbour of element 0 / 1 (the pair partner where mirrored; always a
-                   // valid offset, never-updated elements point at themselves)
-    int go;        // offset of the pair inside a global plane
+    int l0, l1;    // where the pair's elements 0 / 1 live in an LDS plane: pair offset + HSTR * (the element's class)
+    unsigned ldo;  // byte offset of the pair inside a global plane for loads (kDeadLane outside the domain) ...
+    unsigned sto;  // ... and for stores / loads of owned points only (kDeadLane for halo pairs)
+    unsigned ldo1, sto1;  // odd nx: the same for element 1 by itself (the ghost: column nx-2 / kDeadLane)
     int fl;        // bit 0 in-domain, 1 owned, 2/3 element 0/1 inside the x-y update bounds, 4 (ODD) the pair
-                   // of column nx-1 whose element 1 is the ghost, 6 parity
-                   // base, bits 8-11 / 12-15: how many stages element 0 / 1 may take (0: never updated)
+                   // of column nx-1 whose element 1 is the ghost, 6 the pair's parity: class of its element 0
   };
-  auto make_sc = [&](int tid_, int s) {
-    const SlotT q(tid_, s, x0, y0, nxs, ny);
-    SC c;
-    c.lo = SZ * q.lo;
-    c.go = q.i + nx * q.j;
-    // rows whose y neighbours fall outside the loaded tile can never be updated: ring 0
-    const bool yok = q.lj + (q.j == 0 ? 1 : -1) >= 0 && q.lj + (q.j == ny - 1 ? -1 : 1) < TYH;
-    c.yl = !yok ? 0 : ((q.j == 0) ? SZ * NPX : -SZ * NPX);
-    c.yh = !yok ? 0 : ((q.j == ny - 1) ? -SZ * NPX : SZ * NPX);
-    const bool yin = q.j >= g.lb[1] && q.j <= g.ub[1];
-    const bool in0 = yin && q.i >= g.lb[0] && q.i <= g.ub[0];
-    const bool ghost = ODD && q.in && q.i == nx - 1;   // element 1 mirrors column nx-2 (header)
-    const int i1 = ghost ? q.i - 1 : q.i + 1;           // the column element 1 stands for
+  //   cL[c]  the pair inside class c (byte offset into the plane region, buffer offset not included);
+  //   cX[c] / cYH[c] / cYL[c]  the outer x neighbour and the y neighbours of the pair's class-c point (they lie in
+  //   class 1-c; mirrored at the physical faces; the pair partner where the neighbour is outside the tile)
+  //   mU[c]  lanes whose class-c point lies inside the x-y update bounds and the domain;  mP  lanes whose
+  //   element 0 is the class-1 point;  mO  lanes whose pair is owned;  mE[e]  (residual) element e in bounds
+  SC scs[NS];
+  int cL[NS][2], cX[NS][2], cYH[NS][2], cYL[NS][2];
+  unsigned long long mU[NS][2], mP[NS], mO[NS], mE[RES ? NS : 1][2];
+  static_assert(NS <= 2, "tile / thread-count combinations with more than two pairs per thread are not built");
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const SlotT q_(tid, s, x0, y0, nxs, ny);
+    const int lo = SZ * q_.lo;
+    // rows whose y neighbours fall outside the loaded tile (ring 0) read their pair partner instead - any
+    // valid address: what such a point becomes is never used
+    const bool yok = q_.lj + (q_.j == 0 ? 1 : -1) >= 0 && q_.lj + (q_.j == ny - 1 ? -1 : 1) < TYH;
+    const int yl = !yok ? 0 : ((q_.j == 0) ? SZ * NPX : -SZ * NPX);    // mirrored at the physical faces
+    const int yh = !yok ? 0 : ((q_.j == ny - 1) ? -SZ * NPX : SZ * NPX);
+    const bool yin = q_.j >= g.lb[1] && q_.j <= g.ub[1];
+    const bool in0 = yin && q_.i >= g.lb[0] && q_.i <= g.ub[0];
+    const bool ghost = ODD && q_.in && q_.i == nx - 1;   // element 1 mirrors column nx-2 (header)
+    const int i1 = ghost ? q_.i - 1 : q_.i + 1;           // the column element 1 stands for
     const bool in1 = yin && i1 >= g.lb[0] && i1 <= g.ub[0];
-    const bool mir0 = q.i == 0, mir1 = q.i + 1 == nx - 1;
-    const int ry = min(openyl ? q.lj : BIG, openyh ? TYH - 1 - q.lj : BIG);
-    int r0 = min(min(openxl ? q.li : BIG, openxh ? TXH - 1 - q.li : BIG), ry);
-    int r1 = min(min(openxl ? q.li + 1 : BIG, openxh ? TXH - 2 - q.li : BIG), ry);
-    if (ghost) r1 = min(openxl ? q.li - 1 : BIG, ry);   // column nx-2's budget (this tile ends at the face)
-    // the outer x neighbour must be in the tile unless it is mirrored
-    if (!mir0 && q.li - 1 < 0) r0 = 0;
-    if (!mir1 && !ghost && q.li + 2 >= TXH) r1 = 0;
-    if (!yok || !q.in) r0 = r1 = 0;
-    if (!in0) r0 = 0;
-    if (!in1) r1 = 0;
-    c.xlo = mir0 ? c.lo + HALF : (q.li - 1 >= 0 ? c.lo + HALF - SZ : c.lo);
-    c.xhi = mir1 ? c.lo : (q.li + 2 < TXH ? c.lo + SZ : c.lo + HALF);
-    if (ghost) c.xhi = c.lo - SZ;                       // column nx-3: element 0 of the previous pair (li >= HX >= 2)
+    const bool mir0 = q_.i == 0, mir1 = q_.i + 1 == nx - 1;
+    // outer x neighbour of element 0 / 1, as a pair offset in the OTHER class: the pair partner where mirrored
+    // or where the neighbour is outside the tile
+    const int xlo = (!mir0 && q_.li - 1 >= 0) ? lo - SZ : lo;
+    int xhi = (!mir1 && q_.li + 2 < TXH) ? lo + SZ : lo;
+    if (ghost) xhi = lo - SZ;                             // column nx-3: element 0 of the previous pair (li >= HX >= 2)
     // owned = written back by this workgroup: the inner TXI x TYI points, and - in the last tile of a
     // row / column of tiles, whose halo reaches the physical face (launch_cfg counts tiles that way) -
     // the halo points up to that face too: they stay valid through every stage, nothing shrinks there
-    const bool own = q.in && q.li >= HX && q.lj >= NSTG && (q.li < TXH - HX || !openxh) && (q.lj < TYH - NSTG || !openyh);
-    int fl = (q.in ? 1 : 0) | (own ? 2 : 0) | (in0 ? 4 : 0) | (in1 ? 8 : 0) | (ghost ? 16 : 0);
-    fl |= ((q.i + q.j + g.k0 + fp) & 1) ? 64 : 0;
-    fl |= min(r0, 15) << 8;
-    fl |= min(r1, 15) << 12;
-    c.fl = fl;
-    return c;
-  };
-  static_assert(NS <= 2, "tile / thread-count combinations with more than two pairs per thread are not built");
-  static_assert(NSTG <= 15, "stage budget field is 4 bits");
-  SC scs[NS];
+    const bool own = q_.in && q_.li >= HX && q_.lj >= NSTG && (q_.li < TXH - HX || !openxh) && (q_.lj < TYH - NSTG || !openyh);
+    const int par = (q_.i + q_.j + g.k0 + fp) & 1;
+    SC c;
+    const unsigned gob = (unsigned)(q_.i + nx * q_.j) * SZ;
+    c.fl = (q_.in ? 1 : 0) | (own ? 2 : 0) | (in0 ? 4 : 0) | (in1 ? 8 : 0) | (ghost ? 16 : 0) | (par ? 64 : 0);
+    c.l0 = lo + HSTR * par;
+    c.l1 = lo + HSTR - HSTR * par;
+    c.ldo = q_.in ? gob : kDeadLane;
+    c.sto = own ? gob : kDeadLane;
+    c.ldo1 = !q_.in ? kDeadLane : (ghost ? gob - SZ : gob + SZ);
+    c.sto1 = (own && !ghost) ? gob + SZ : kDeadLane;
+    scs[s] = c;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) scs[s] = make_sc(tid, s);
+    for (int cl = 0; cl < 2; ++cl) {
+      const int e = cl ^ par;   // the element of class cl
+      cL[s][cl] = lo + cl * HSTR;
+      cX[s][cl] = (e ? xhi : xlo) + (1 - cl) * HSTR;
+      cYH[s][cl] = lo + yh + (1 - cl) * HSTR;
+      cYL[s][cl] = lo + yl + (1 - cl) * HSTR;
+      // NOT part of the mask: how many stages a halo point stays valid for (ring r: r stages).  A point beyond
+      // that takes a meaningless value, but no point still inside ITS count ever reads it - a neighbour one
+      // ring further in has one stage more and by then reads what the previous stage left - and halo points are
+      // never stored.  The same holds along z for the chunk's warm-up and drain planes.  What must never change
+      // is DATA: points outside the update bounds and the domain.
+      mU[s][cl] = __builtin_amdgcn_ballot_w64(q_.live && q_.in && (e ? in1 : in0));
+    }
+    mP[s] = __builtin_amdgcn_ballot_w64(par != 0);
+    mO[s] = __builtin_amdgcn_ballot_w64(own);
+    if (RES) {
+      mE[RES ? s : 0][0] = __builtin_amdgcn_ballot_w64(in0);
+      mE[RES ? s : 0][1] = __builtin_amdgcn_ballot_w64(in1);
+    }
+  }
   char *const ldsb = reinterpret_cast<char *>(lds);
 #define LDSD(off) (*reinterpret_cast<T *>(ldsb + (off)))
+  // element order <-> class order of a pair (what a lane whose element 0 is the class-1 point swaps)
+  auto by_class = [&](const d2 v, int s_) {
+    const bool sw = __builtin_amdgcn_inverse_ballot_w64(mP[s_]);
+    d2 r;
+    r.x = sw ? v.y : v.x;
+    r.y = sw ? v.x : v.y;
+    return r;
+  };
+
 
   // ---- PROL: coarse footprint of the tile, per-thread interpolation constants ----
   constexpr int CW = TXH / 2 + 3, CH = TYH / 2 + 3;  // coarse points the tile can touch (ratio >= ~1.97)
   constexpr int NCS = PROL ? (CW * CH + NT - 1) / NT : 1;
   // z-interpolated coarse planes, double buffered: the plane of fine plane kf sits in tile kf & 1,
   // parked one iteration before it is needed so that the correction runs before the barrier
-  double *const czt0 = reinterpret_cast<double *>(ldsb + NSTG * PLANE * SZ);
+  double *const czt0 = reinterpret_cast<double *>(ldsb + NB * PLANE * SZ);
+  // the x / y interpolation weights of the tile's columns and rows sit in LDS behind the parked planes
+  // ([NPX][wl0, wh0, wl1, wh1], [TYH][wl, wh]; zero outside the domain): per slot they would take 24 registers
+  // the kernel does not have - three 16-byte LDS reads per pair and plane instead
+  double *const pwx = czt0 + 2 * CW * CH;
+  double *const pwy = pwx + 4 * NPX;
+  int p_xa[PROL ? NS : 1], p_ya[PROL ? NS : 1];   // the slot's entries (element offsets)
   int cx0 = 0, cy0 = 0, kcur = 0;
-  int p_il[PROL ? NS : 1][2], p_jl[PROL ? NS : 1];
-  double p_wlx[PROL ? NS : 1][2], p_whx[PROL ? NS : 1][2], p_wly[PROL ? NS : 1], p_why[PROL ? NS : 1];
+  // position of a pair in the parked coarse tile, packed into one register per slot: 4 * (row * CW + column of
+  // element 0's lower bracket) + (element 1's bracket column - element 0's + 1); the difference is 0 or 1 (-1 or 0
+  // for the odd-nx ghost)
+  int p_o[PROL ? NS : 1];
   double c_lo[NCS], c_hi[NCS], c_nx[NCS];
-  size_t c_off[NCS];
+  int c_off[NCS];   // (a coarse plane of the fused path's levels has far fewer than 2^31 points: launch_rbgs3_fused checks)
   bool c_ok[NCS];
   if (PROL) {
     const int ia = max(x0, 0), ja = max(y0, 0);
@@ -396,24 +462,35 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 #pragma unroll
     for (int s = 0; s < (PROL ? NS : 1); ++s) {
       const SlotT q(tid, s, x0, y0, nxs, ny);
-      p_jl[s] = 0;
-      p_wly[s] = p_why[s] = 0.0;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        p_il[s][h] = 0;
-        p_wlx[s][h] = p_whx[s][h] = 0.0;
-      }
+      p_o[s] = 1;
+      p_xa[s] = 4 * (q.li / 2);
+      p_ya[s] = 2 * q.lj;
       if (q.in) {
-        p_jl[s] = pa.plo[1][q.j] - cy0;
-        p_wly[s] = pa.pwl[1][q.j];
-        p_why[s] = pa.pwh[1][q.j];
+        const int jl = pa.plo[1][q.j] - cy0;
+        int il[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int ih = (ODD && q.i + h >= nx) ? q.i - 1 : q.i + h;   // the ghost gets column nx-2's correction
-          p_il[s][h] = pa.plo[0][ih] - cx0;
-          p_wlx[s][h] = pa.pwl[0][ih];
-          p_whx[s][h] = pa.pwh[0][ih];
+          il[h] = pa.plo[0][ih] - cx0;
         }
+        p_o[s] = 4 * (jl * CW + il[0]) + (il[1] - il[0] + 1);
+      }
+    }
+    for (int t = tid; t < NPX + TYH; t += NT) {
+      if (t < NPX) {
+        const int i = x0 + 2 * t;                       // the pair of columns i, i+1 (same test as Slot::in)
+        const bool ok = i >= 0 && i + 1 < nxs;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ih = (ODD && i + h >= nx) ? i - 1 : i + h;
+          pwx[4 * t + 2 * h] = ok ? pa.pwl[0][ih] : 0.0;
+          pwx[4 * t + 2 * h + 1] = ok ? pa.pwh[0][ih] : 0.0;
+        }
+      } else {
+        const int j = y0 + (t - NPX);
+        const bool ok = j >= 0 && j < ny;
+        pwy[2 * (t - NPX)] = ok ? pa.pwl[1][j] : 0.0;
+        pwy[2 * (t - NPX) + 1] = ok ? pa.pwh[1][j] : 0.0;
       }
     }
 #pragma unroll
@@ -421,7 +498,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       const int idx = tid + NT * c;
       const int a = idx % CW, b = idx / CW;
       c_ok[c] = b < CH && cx0 + a < pa.ncx && cy0 + b < pa.ncy;
-      c_off[c] = c_ok[c] ? (size_t)(cx0 + a) + (size_t)pa.ncx * (size_t)(cy0 + b) : 0;
+      c_off[c] = c_ok[c] ? (cx0 + a) + pa.ncx * (cy0 + b) : 0;
       c_lo[c] = c_hi[c] = c_nx[c] = 0.0;
     }
   }
@@ -506,16 +583,19 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 #pragma unroll
     for (int s = 0; s < (PROL ? NS : 1); ++s) {
       if (!(scs[s].fl & 1)) continue;
-      const double *r0 = czt + p_jl[s] * CW, *r1 = r0 + CW;
+      const double *r0 = czt + (p_o[s] >> 2), *r1 = r0 + CW;
+      const double2 wy = *reinterpret_cast<const double2 *>(pwy + p_ya[s]);          // wl, wh of the row
+      const double2 wx0 = *reinterpret_cast<const double2 *>(pwx + p_xa[s]);         // wl, wh of element 0
+      const double2 wx1 = *reinterpret_cast<const double2 *>(pwx + p_xa[s] + 2);     // ... of element 1
       double v[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int il = p_il[s][h];
+        const int il = h ? (p_o[s] & 3) - 1 : 0;
         double f0 = r0[il], f1 = r0[il + 1];
         const double f2 = r1[il], f3 = r1[il + 1];
-        f0 = p_why[s] * f0 + p_wly[s] * f2;
-        f1 = p_why[s] * f1 + p_wly[s] * f3;
-        v[h] = p_whx[s][h] * f0 + p_wlx[s][h] * f1;
+        f0 = wy.y * f0 + wy.x * f2;
+        f1 = wy.y * f1 + wy.x * f3;
+        v[h] = (h ? wx1.y : wx0.y) * f0 + (h ? wx1.x : wx0.x) * f1;
       }
       pl_[s].x = (T)((double)pl_[s].x + v[0]);
       pl_[s].y = (T)((double)pl_[s].y + v[1]);
@@ -530,7 +610,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       d2 r0[NS];
       NDSM_LOAD_PLANE(rhs, ks, r0);
 #pragma unroll
-      for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rw[s][0] = r0[s];
+      for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rw[s][0] = by_class(r0[s], s);
     }
     if (ks + 1 <= ke) NDSM_LOAD_PLANE(u, ks + 1, nxt);
     if (PROL) {  // the two planes loaded here get their correction here
@@ -549,13 +629,12 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       __syncthreads();
       if (ks + 2 <= ke) prol_stage(ks + 2);  // for the first iteration; published by the barrier below
     }
-    T *B0 = lds + (ks % NSTG) * PLANE;
+    char *const B0 = ldsb + (ks % NB) * HALF;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const SlotT q(tid, s, x0, y0, nxs, ny);
-      if (q.live) {
-        B0[q.lo] = c0[s].x;
-        B0[NPAIR + q.lo] = c0[s].y;
+      if (tid0 + NT * s < NPAIR) {
+        *reinterpret_cast<T *>(B0 + scs[s].l0) = c0[s].x;
+        *reinterpret_cast<T *>(B0 + scs[s].l1) = c0[s].y;
       }
     }
   }
@@ -563,189 +642,171 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 
   const int klast = ze + NSTG - 2;  // iteration in which the last stage reaches plane ze-1
   double met_mx = 0.0, met_sm = 0.0;
-  int kb = ks % NSTG;               // LDS buffer of plane k (RES: NSTG is not a power of two)
-  for (int k = ks; k <= klast; ++k) {
-    // byte offset of the LDS buffer of plane k - d, -1 <= d <= NSTG
-    auto bufoff = [&](int d) {
-      int b;
-      if ((NSTG & (NSTG - 1)) != 0) {   // pipeline depth not a power of two (residual stage, three sweeps)
-        b = kb - d;
-        b = b < 0 ? b + NSTG : b;
-        b = b >= NSTG ? b - NSTG : b;
-      } else {
-        b = (k - d) & (NST - 1);
-      }
-      return b * (PLANE * SZ);
-    };
+  // z range in which a stage plane is an ordinary one: inside the update bounds and off the mirror faces
+  const int zin0 = max(g.lb[2], 1 - g.k0), zin1 = min(g.ub[2], g.nzg - 2 - g.k0);
+  // One plane-step.  The copy C of the step serves the iterations k = C (mod NCOPY): plane k-d sits in LDS buffer
+  // (C - d) mod NB, every stage updates class C & 1.
+  constexpr int NCOPY = (NB % 2 == 0) ? NB : 2 * NB;
+  auto plane_step = [&](const int k, auto CT) __attribute__((always_inline)) {
+    constexpr int C = decltype(CT)::value;
+    constexpr int HK = C & 1;
+#define NDSM_BO(d) (((((C - (d)) % NB) + NB) % NB) * HALF)
     // PROL: park the z-interpolated coarse plane of fine plane k+3 (the other tile: plane k+2's
     // was parked an iteration ago and is read further down, before the barrier).  BEFORE this
     // iteration's loads are issued: it consumes a prefetched coarse plane, and a vmcnt wait placed
     // after the new loads would wait for those too.
     if (PROL && k + 3 <= ke) prol_stage(k + 3);
-    // request plane k+2 of u and plane k+1 of rhs before touching plane k
-    if (k + 2 <= ke) {
-      const T *pk = u + sz * (size_t)(k + 2);
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-        if (scs[s].fl & 1) nn[s] = ldpair(pk + scs[s].go, scs[s].fl);
-    }
-    if (!RHS0 && k + 1 <= ke) {
-      const T *pk = rhs + sz * (size_t)(k + 1);
-#pragma unroll
-      for (int s = 0; s < (RHS0 ? 1 : NS); ++s)
-        if (scs[s].fl & 1) rn[s] = ldpair(pk + scs[s].go, scs[s].fl);
-    }
-
-
-    // MET: the previous iterate of the plane this iteration will store
+    const int pf = k - (NST - 1);          // the plane that leaves the smoothing stages in this step
+    const bool pf_st = pf >= zs && pf < ze;
+    const int pr = k - NST;                // RES: the plane whose residual is formed
+    const bool pr_st = RES && pr >= zs && pr < ze;
+    // MET: the previous iterate of plane pf; plane k+1 of rhs; plane k+2 of u - requested before plane k is touched
     d2 pvh[MET ? NS : 1];
     if (MET) {
-      const int pf = k - (NST - 1);
+      const auto rp = rsrc_of(prev, pf, pf_st);
 #pragma unroll
-      for (int s = 0; s < (MET ? NS : 1); ++s) {
-        pvh[s].x = pvh[s].y = 0.0;
-        if (pf >= zs && pf < ze && (scs[s].fl & 2)) pvh[s] = ldpair(prev + sz * (size_t)pf + scs[s].go, scs[s].fl);
-      }
+      for (int s = 0; s < (MET ? NS : 1); ++s) pvh[s] = ldp(rp, scs[s].sto, scs[s].sto1);
+    }
+    if (!RHS0) {
+      const auto rr_ = rsrc_of(rhs, k + 1, k + 1 <= ke);
+#pragma unroll
+      for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rn[s] = ldp(rr_, scs[s].ldo, scs[s].ldo1);
+    }
+    {
+      const auto ru = rsrc_of(u, k + 2, k + 2 <= ke);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) nn[s] = ldp(ru, scs[s].ldo, scs[s].ldo1);
     }
 
-    // ---- this iteration's element of every pair (the same for all stages) ----
-    int ee[NS], eB[NS], oB[NS], xB[NS], lim[NS];
-    T zplus[NS];
+    // ---- the stages ----
+    // z+1 neighbour of the first stage: the class-HK point of plane k+1, still in registers; the later stages
+    // read theirs back from LDS - what the stage before left there, or the old value where it did not write
+    T zp[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const SC c = scs[s];
-      const int e = ((c.fl >> 6) + k) & 1;
-      ee[s] = e;
-      eB[s] = c.lo + HALF * e;      // the element, its pair partner, its outer x neighbour
-      oB[s] = c.lo + HALF - HALF * e;
-      xB[s] = e ? c.xhi : c.xlo;
-      lim[s] = (c.fl >> (8 + 4 * e)) & 15;  // stage t may update it iff lim > t
-      zplus[s] = pick(nxt[s], e);           // plane k+1, untouched by any stage yet
+      const d2 nc = by_class(nxt[s], s);
+      zp[s] = HK ? nc.y : nc.x;
     }
-
-    // ---- the stages, both slots side by side: loads, arithmetic, write-back ----
+    // ZB: a stage plane of this step lies outside the z update bounds or on a mirror face (a handful of steps
+    // per launch): those stages do not write / take the mirrored neighbour.  Stage planes that do not exist
+    // (below plane 0, above the last plane) are outside the bounds.
+    auto stages = [&](auto ZBT) __attribute__((always_inline)) {
+      constexpr bool ZB = decltype(ZBT)::value;
 #pragma unroll
-    for (int t = 0; t < NST; ++t) {
-      const int p = k - t;  // plane of this stage
-      // stage t covers planes [zs-(NSTG-1-t), ze-1+(NSTG-1-t)] of the chunk (uniform test)
-      const bool act = p >= max(zs - (NSTG - 1 - t), 0) && p <= min(ze - 1 + (NSTG - 1 - t), nz - 1);
-      if (!act) continue;
-      const int bB = bufoff(t);
-      const int bZ = bufoff(t + 1);
-      const bool pin = p >= g.lb[2] && p <= g.ub[2];
-      const int pg = p + g.k0;
-      T cur[NS], oth[NS], xn[NS], yhv[NS], ylv[NS], zm[NS];
+      for (int t = 0; t < NST; ++t) {
+        const int bB = NDSM_BO(t), bZ = NDSM_BO(t + 1);
+        T oth[NS], xn[NS], yhv[NS], ylv[NS], zm[NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        cur[s] = LDSD(bB + eB[s]);
-        oth[s] = LDSD(bB + oB[s]);
-        xn[s] = LDSD(bB + xB[s]);
-        yhv[s] = LDSD(bB + eB[s] + scs[s].yh);
-        ylv[s] = LDSD(bB + eB[s] + scs[s].yl);
-        // plane p-1: its LDS copy, or (last stage) the saved final element
-        zm[s] = (t < NSTG - 1) ? LDSD(bZ + eB[s]) : mLe[RES ? 0 : s];
+        for (int s = 0; s < NS; ++s) {
+          if (t > 0) zp[s] = LDSD(cL[s][HK] + NDSM_BO(t - 1));
+          oth[s] = LDSD(cL[s][1 - HK] + bB);
+          xn[s] = LDSD(cX[s][HK] + bB);
+          yhv[s] = LDSD(cYH[s][HK] + bB);
+          ylv[s] = LDSD(cYL[s][HK] + bB);
+          // plane k-t-1: its LDS copy, or (last stage) the saved final point
+          zm[s] = (t < NSTG - 1) ? LDSD(cL[s][HK] + bZ) : mLe[RES ? 0 : s];
+        }
+        const int pg = k - t + g.k0;
+        const bool wr = !ZB || (k - t >= g.lb[2] && k - t <= g.ub[2]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const T xs = oth[s] + xn[s];  // u(xh) + u(xl)
+          const T ys = yhv[s] + ylv[s];
+          const T zhv = (ZB && pg == g.nzg - 1) ? zm[s] : zp[s];
+          const T zlv = (ZB && pg == 0) ? zp[s] : zm[s];
+          const T zsum = zhv + zlv;
+          const T rr = RHS0 ? (T)0 : (HK ? rw[RHS0 ? 0 : s][RHS0 ? 0 : t].y : rw[RHS0 ? 0 : s][RHS0 ? 0 : t].x);
+          const T unew = xs * gw0 + ys * gw1 + zsum * gw2 - rr;
+          const T nw = gw1i * unew;
+          if (wr && __builtin_amdgcn_inverse_ballot_w64(mU[s][HK])) LDSD(cL[s][HK] + bB) = nw;
+        }
       }
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const T xs = oth[s] + xn[s];  // u(xh) + u(xl)
-        const T ys = yhv[s] + ylv[s];
-        const T zhv = (pg == g.nzg - 1) ? zm[s] : zplus[s];
-        const T zlv = (pg == 0) ? zplus[s] : zm[s];
-        const T zsum = zhv + zlv;
-        const T rr = RHS0 ? (T)0 : pick(rw[RHS0 ? 0 : s][RHS0 ? 0 : t], ee[s]);
-        const T unew = xs * gw0 + ys * gw1 + zsum * gw2 - rr;
-        const T nw = gw1i * unew;
-        const bool upd = pin && lim[s] > t;
-        if (upd) LDSD(bB + eB[s]) = nw;
-        zplus[s] = upd ? nw : cur[s];  // z+1 neighbour of the next stage's plane
-      }
-    }
+    };
+    if (pf >= zin0 && k <= zin1)
+      stages(std::false_type());
+    else
+      stages(std::true_type());
 
     // PROL: the correction of the plane that arrived during the stages (its coarse plane was parked
     // one iteration ago), done here so that it overlaps with other waves' stages
     if (PROL && k + 2 <= ke) prol_corr(nn, k + 2);
 
-    // Results of this iteration that go to HBM.  DEFER: they are STORED only after the window shift
-    // below has consumed the loads of plane k+2: vmcnt counts stores as well, and a store issued
-    // just before that wait would put its whole round trip on the critical path of every plane
-    // (measured: -5 % on the two-sweep launch; the sweep+residual launch is better off storing at once).
+    // Plane pf has passed its last stage: it goes to HBM; the next step's last stage needs its class-(1-HK)
+    // point.  DEFER: it is STORED only after the window shift below has consumed the loads of plane k+2: vmcnt
+    // counts stores as well, and a store issued just before that wait would put its whole round trip on the
+    // critical path of every plane (-5 % on the two-sweep launch; the sweep+residual launch stores at once).
     d2 finh[NS], resh[RES ? NS : 1];
-    bool fin_st[NS], res_st[RES ? NS : 1];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const SC c = scs[s];
-      const int fl = c.fl;
-      // plane k-NST+1 has passed its last stage: store it, keep what the next
-      // iteration's last stage needs from it (its other element, already final)
-      const int pf = k - (NST - 1);
-      d2 fin;
-      fin.x = fin.y = 0.0;
-      fin_st[s] = false;
-      if (pf >= ks) {
-        fin.x = LDSD(bufoff(NST - 1) + c.lo);
-        fin.y = LDSD(bufoff(NST - 1) + c.lo + HALF);
-        fin_st[s] = pf >= zs && pf < ze && (fl & 2);
-        if (!DEFER && fin_st[s]) stpair(uout + sz * (size_t)pf + c.go, fin, fl);
-        if (!RES) mLe[RES ? 0 : s] = pick(fin, 1 - ee[s]);
+      finh[s].x = LDSD(scs[s].l0 + NDSM_BO(NST - 1));
+      finh[s].y = LDSD(scs[s].l1 + NDSM_BO(NST - 1));
+      if (!RES) {
+        const d2 fc = by_class(finh[s], s);
+        mLe[RES ? 0 : s] = HK ? fc.x : fc.y;
       }
-      finh[s] = fin;
+    }
+    if (RES) {
+      // residual of plane pr: centre f1, below f2, above finh (all final); same expression as residual.hip
+      const int bR = NDSM_BO(NST);
+      const int prg = pr + g.k0;
+      const bool inz = pr >= g.lb[2] && pr <= g.ub[2];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int f = RES ? s : 0;
+        const d2 cc = f1[f], below = f2[f], fin = finh[s];
+        // (element 0 is the point of class par, element 1 that of class 1 - par)
+        const bool pr1 = __builtin_amdgcn_inverse_ballot_w64(mP[s]);
+        const T xl0 = LDSD(bR + (pr1 ? cX[s][1] : cX[s][0]));
+        const T xh1 = LDSD(bR + (pr1 ? cX[s][0] : cX[s][1]));
+        d2 vl, vh;
+        vl.x = LDSD(bR + (pr1 ? cYL[s][1] : cYL[s][0]));
+        vl.y = LDSD(bR + (pr1 ? cYL[s][0] : cYL[s][1]));
+        vh.x = LDSD(bR + (pr1 ? cYH[s][1] : cYH[s][0]));
+        vh.y = LDSD(bR + (pr1 ? cYH[s][0] : cYH[s][1]));
+        const d2 wl = (prg == 0) ? fin : below;
+        const d2 wh = (prg == g.nzg - 1) ? below : fin;
+        d2 rr;
+        rr.x = rr.y = 0.0;
+        if (!RHS0) rr = by_class(rw[RHS0 ? 0 : s][(RHS0 || !RES) ? 0 : NST], s);   // (the swap is its own inverse)
+        const T v0 = (xl0 + cc.y) * gw0 + (vl.x + vh.x) * gw1 + (wl.x + wh.x) * gw2 - rr.x - cc.x * gwc;
+        const T v1 = (cc.x + xh1) * gw0 + (vl.y + vh.y) * gw1 + (wl.y + wh.y) * gw2 - rr.y - cc.y * gwc;
+        d2 res;
+        res.x = (inz && __builtin_amdgcn_inverse_ballot_w64(mE[f][0])) ? -v0 : (T)0;
+        res.y = (inz && __builtin_amdgcn_inverse_ballot_w64(mE[f][1])) ? -v1 : (T)0;
+        resh[f] = res;
+        f2[f] = cc;
+        f1[f] = fin;
+      }
+    }
+    if (!DEFER) {   // (planes outside the store window: a descriptor of zero records, nothing is written)
+      const auto rs_ = rsrc_of(uout, pf, pf_st);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) stp(rs_, scs[s].sto, scs[s].sto1, finh[s]);
       if (RES) {
-        // residual of plane k-NST: centre f1, below f2, above fin (all final)
-        const int pr = k - NST;
-        const d2 cc = f1[RES ? s : 0], below = f2[RES ? s : 0];
-        res_st[RES ? s : 0] = pr >= zs && pr < ze && (fl & 2);
-        resh[RES ? s : 0].x = resh[RES ? s : 0].y = 0.0;
-        if (res_st[RES ? s : 0]) {
-          const int bR = bufoff(NST);
-          const T xl0 = LDSD(bR + c.xlo);
-          const T xh1 = LDSD(bR + c.xhi);
-          d2 vl, vh;
-          vl.x = LDSD(bR + c.lo + c.yl);
-          vl.y = LDSD(bR + c.lo + HALF + c.yl);
-          vh.x = LDSD(bR + c.lo + c.yh);
-          vh.y = LDSD(bR + c.lo + HALF + c.yh);
-          const int prg = pr + g.k0;
-          const d2 wl = (prg == 0) ? fin : below;
-          const d2 wh = (prg == g.nzg - 1) ? below : fin;
-          const bool inz = pr >= g.lb[2] && pr <= g.ub[2];
-          d2 rr;
-          rr.x = rr.y = 0.0;
-          if (!RHS0) rr = rw[RHS0 ? 0 : s][(RHS0 || !RES) ? 0 : NST];
-          const T v0 = (xl0 + cc.y) * gw0 + (vl.x + vh.x) * gw1 + (wl.x + wh.x) * gw2 - rr.x - cc.x * gwc;
-          const T v1 = (cc.x + xh1) * gw0 + (vl.y + vh.y) * gw1 + (wl.y + wh.y) * gw2 - rr.y - cc.y * gwc;
-          d2 res;
-          res.x = (inz && (fl & 4)) ? -v0 : (T)0;
-          res.y = (inz && (fl & 8)) ? -v1 : (T)0;
-          if (DEFER)
-            resh[RES ? s : 0] = res;
-          else
-            stpair(rout + sz * (size_t)pr + c.go, res, fl);
-        }
-        f2[RES ? s : 0] = cc;
-        f1[RES ? s : 0] = fin;
+        const auto rr_ = rsrc_of(rout, pr, pr_st);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) stp(rr_, scs[s].sto, scs[s].sto1, resh[RES ? s : 0]);
       }
     }
 
     __syncthreads();  // every stage is done with its plane
 
-    // ---- plane k+1 takes the LDS buffer of plane k-NSTG+1; shift the windows ----
-    {
-      char *bn = ldsb + bufoff(-1);
+    // ---- plane k+1 takes the LDS buffer of the plane that has just left; shift the windows ----
+    // (past the chunk's last plane the buffer load returned zeros: written, never used)
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        if (k + 1 <= ke && tid0 + NT * s < NPAIR) {
-          *reinterpret_cast<T *>(bn + scs[s].lo) = nxt[s].x;
-          *reinterpret_cast<T *>(bn + scs[s].lo + HALF) = nxt[s].y;
-        }
-        nxt[s] = nn[s];
+    for (int s = 0; s < NS; ++s) {
+      if (tid0 + NT * s < NPAIR) {
+        LDSD(scs[s].l0 + NDSM_BO(-1)) = nxt[s].x;
+        LDSD(scs[s].l1 + NDSM_BO(-1)) = nxt[s].y;
       }
-      if (!RHS0) {
+      nxt[s] = nn[s];
+    }
+    if (!RHS0) {
 #pragma unroll
-        for (int s = 0; s < (RHS0 ? 1 : NS); ++s) {
+      for (int s = 0; s < (RHS0 ? 1 : NS); ++s) {
 #pragma unroll
-          for (int t = (RHS0 ? 1 : NSTG) - 1; t > 0; --t) rw[s][t] = rw[s][t - 1];
-          rw[s][0] = rn[s];
-        }
+        for (int t = (RHS0 ? 1 : NSTG) - 1; t > 0; --t) rw[s][t] = rw[s][t - 1];
+        rw[s][0] = by_class(rn[s], s);
       }
     }
     // ---- now the global stores: they have a whole iteration before the next vmcnt wait ----
@@ -754,21 +815,51 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     if (DEFER) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(nxt[s].x), "v"(nxt[s].y) : "memory");
-    }
+      if (MET && pf_st) {
 #pragma unroll
-    for (int s = 0; s < (DEFER ? NS : 0); ++s) {
-      if (MET && fin_st[s]) {
-        const double d0 = fabs((double)finh[s].x - (double)pvh[MET ? s : 0].x);
-        const double d1 = (ODD && (scs[s].fl & 16)) ? 0.0 : fabs((double)finh[s].y - (double)pvh[MET ? s : 0].y);
-        met_mx = fmax(met_mx, fmax(d0, d1));
-        met_sm = met_sm + d0;
-        met_sm = met_sm + d1;
+        for (int s = 0; s < NS; ++s) {
+          if (__builtin_amdgcn_inverse_ballot_w64(mO[s])) {
+            const d2 pv = pvh[MET ? s : 0];
+            const double d0 = fabs((double)finh[s].x - (double)pv.x);
+            const double d1 = (ODD && (scs[s].fl & 16)) ? 0.0 : fabs((double)finh[s].y - (double)pv.y);
+            met_mx = fmax(met_mx, fmax(d0, d1));
+            met_sm = met_sm + d0;
+            met_sm = met_sm + d1;
+          }
+        }
       }
-      if (fin_st[s]) stpair(uout + sz * (size_t)(k - (NST - 1)) + scs[s].go, finh[s], scs[s].fl);
-      if (RES && res_st[RES ? s : 0]) stpair(rout + sz * (size_t)(k - NST) + scs[s].go, resh[RES ? s : 0], scs[s].fl);
+      {
+        const auto rs_ = rsrc_of(uout, pf, pf_st);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) stp(rs_, scs[s].sto, scs[s].sto1, finh[s]);
+      }
     }
-    kb = (kb + 1 == NSTG) ? 0 : kb + 1;
     __syncthreads();
+#undef NDSM_BO
+  };
+  {
+    int kc = ks % NCOPY;   // which copy serves step k
+#pragma unroll 1
+    for (int k = ks; k <= klast; ++k) {
+      // (exactly NCOPY copies of the step)
+      if (kc == 0) {
+        plane_step(k, std::integral_constant<int, 0>());
+      } else if (kc == 1) {
+        plane_step(k, std::integral_constant<int, 1>());
+      } else if constexpr (NCOPY > 2) {
+        if (kc == 2) {
+          plane_step(k, std::integral_constant<int, 2 % NCOPY>());
+        } else if (kc == 3) {
+          plane_step(k, std::integral_constant<int, 3 % NCOPY>());
+        } else if constexpr (NCOPY > 4) {
+          if (kc == 4)
+            plane_step(k, std::integral_constant<int, 4 % NCOPY>());
+          else
+            plane_step(k, std::integral_constant<int, 5 % NCOPY>());
+        }
+      }
+      kc = (kc + 1 == NCOPY) ? 0 : kc + 1;
+    }
   }
   if (MET) {
     __shared__ double smx[NT / 64], ssm[NT / 64];
@@ -868,7 +959,8 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
   pl.nty = g.n[1] > NST ? (g.n[1] - NST + TYI - 1) / TYI : 1;
   const int tiles = pl.ntx * pl.nty;
   const int nzo = g.zown1 - g.zown0;  // owned planes
-  const size_t lds_bytes = sizeof(T) * NST * TXH * TYH + (MODE == 3 ? 2 * sizeof(double) * (TXH / 2 + 3) * (TYH / 2 + 3) : 0);
+  const size_t lds_bytes = sizeof(T) * NST * TXH * TYH +
+                           (MODE == 3 ? sizeof(double) * (2 * (TXH / 2 + 3) * (TYH / 2 + 3) + 2 * TXH + 2 * TYH) : 0);
   static int attr_epoch[2] = {0, 0};   // per instantiation and device epoch (ndsmk_init may re-target)
   static int wgs_per_cu[2] = {1, 1};
   const int v = rhs ? 0 : 1;
@@ -971,6 +1063,8 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   if (met_done) *met_done = 0;
   if (!uout || g.ndim != 3 || ((g.n[0] & 1) != 0) != ODD || g.n[0] < 16 || g.n[1] < 16 || g.zown1 - g.zown0 < (force ? 1 : 8))
     return 0;
+  // the buffer path addresses a plane with 32-bit byte offsets below kDeadLane (2 GiB: 16384 x 16384 doubles)
+  if ((int64_t)g.n[0] * g.n[1] * (int64_t)sizeof(T) >= (int64_t)kDeadLane) return 0;
   // a z-streaming workgroup walks >= 16 planes serially: with fewer than ~one
   // workgroup per CU the sweep is latency bound and the two colour passes win
   const int64_t npts = (int64_t)g.n[0] * g.n[1] * (g.zown1 - g.zown0);
@@ -1099,7 +1193,8 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
     pa.nzf = px->nf[2];
     pa.ck0 = px->c_k0;
     pa.nczw = (px->f_k0 == 0 && px->c_k0 == 0 && px->nf[2] == g.n[2]) ? px->nc[2] : px->c_cnt;
-    if (px->f_k0 != g.k0 || px->nf[0] != g.n[0] || px->nf[1] != g.n[1] || px->nf[2] != g.nzg || pa.nczw < 1) {
+    if (px->f_k0 != g.k0 || px->nf[0] != g.n[0] || px->nf[1] != g.n[1] || px->nf[2] != g.nzg || pa.nczw < 1 ||
+        (int64_t)pa.ncx * pa.ncy >= ((int64_t)1 << 31)) {
       *sweeps_done = 0;
       return 0;
     }
