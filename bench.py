@@ -16,13 +16,18 @@ value = fine-grid lattice-point updates per second over the WHOLE V-cycle:
         as overhead, not as updates).
 Extra keys: vcycles_per_s, smoother (kernel-only, HIP events on the library
 stream), roofline = the kernel that dominates the timed region (two-sweep
-Laplace launch of level 1, 16 B/LUP algorithmic; frac_algorithmic and frac_hbm
-side by side), roofline_general_rhs (the same launch with a right-hand side in
-HBM, 24 B/LUP), solve (whole Ax solve to vc_tol=1e-10), end_to_end
-(ndsm_vector_solve wall time, host buffers in and out), cpu_baseline (the
-reference itself on this box's host cores, on the same 512^3 grid).
+Laplace launch of level 1): achieved / frac = HBM bytes the launch really moved
+(rocprofv3 counters, measured in this run) / launch time / 8 TB/s, with the
+algorithmic figure (16 B/LUP x 2 sweeps) beside it as frac_algorithmic;
+roofline_general_rhs (the same launch with a right-hand side in HBM), solve
+(whole Ax solve to vc_tol=1e-10), configs (BASELINE configs 0, 1, 3 on this GPU),
+end_to_end / end_to_end_small (ndsm_vector_solve wall time, host buffers in and
+out), cpu_baseline (the reference itself on this box's host cores, same grid).
 
-One process per GPU.  N > 1: see DESIGN.md section "multi-GPU".
+One process per GPU.  `python3 bench.py --gpus N` without a launcher starts its
+own N ranks (torch.distributed.run as a child, before anything touches a GPU)
+and relays rank 0's line; under a launcher (WORLD_SIZE set) it is one rank.
+N > 1: see DESIGN.md section "multi-GPU".
 """
 import argparse
 import json
@@ -39,6 +44,60 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_LUP = 24.0       # u read + rhs read + u write per full red+black sweep
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def run_child(cmd, timeout_s, **kw):
+    """subprocess.run in a process group of its own; whatever the child leaves behind (profiler helpers,
+    launcher agents) is ended with the group, so that nothing this bench started outlives it"""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True, **kw)
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        out, err = p.communicate()
+        return 124, out, err
+    finally:
+        try:
+            os.killpg(p.pid, signal.SIGTERM)      # the group leader has exited: only stragglers are left
+        except OSError:
+            pass
+    return p.returncode, out, err
+
+
+def spawn_ranks(args):
+    """`python3 bench.py --gpus N` as a lone process: start the N ranks (one per GPU) under torch.distributed.run
+    as a CHILD - this process has not loaded the library or touched a GPU - relay rank 0's JSON line, return
+    the launcher's exit code (non-zero if any rank failed)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    rc, out, err = run_child(cmd, 3000, env=env, cwd=ROOT)
+    sys.stderr.write(err[-20000:])
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        rc = 3
+    return rc
 
 
 def boundary_problem(n):
@@ -82,7 +141,8 @@ def cpu_baseline(n=512, seconds_budget=8.0):
         if el > seconds_budget or sweeps >= 2000:
             break
     per_sweep = el / sweeps
-    out = {"value": n ** 3 / per_sweep, "unit": "LUP/s", "cores": orc.threads, "kind": kind, "grid": f"{n}^3",
+    out = {"value": n ** 3 / per_sweep, "unit": "LUP/s", "cores": orc.threads, "cpu_model": cpu_model(), "kind": kind,
+           "grid": f"{n}^3",
            "sample": f"{sweeps} sweeps of red_black_gauss_3D at {n}^3 (the benchmarked grid), BCs NDDNDD, "
                      f"OMP_NUM_THREADS={orc.threads} ({usable_cpus(10**6)} usable host CPUs)",
            "ms_per_sweep": per_sweep * 1e3}
@@ -108,7 +168,6 @@ def live_traffic(n, zero_rhs, kernel_sub, timeout_s=75):
     import csv
     import glob
     import shutil
-    import subprocess
     import tempfile
     exe = shutil.which("rocprofv3")
     if not exe:
@@ -122,11 +181,10 @@ def live_traffic(n, zero_rhs, kernel_sub, timeout_s=75):
             d = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--",
                    sys.executable, os.path.join(ROOT, "scripts", "run_sweeps.py"), str(n), "7"] + (["zero"] if zero_rhs else [])
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s,
-                               cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"))
+            rc_, _o, _e = run_child(cmd, timeout_s, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"))
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
+            if rc_ != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {rc_})"
             got = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
                    if row["Counter_Name"] == ctr and kernel_sub in row["Kernel_Name"].replace(" ", "")]
             if not got:
@@ -144,15 +202,13 @@ def live_traffic(n, zero_rhs, kernel_sub, timeout_s=75):
 def end_to_end_fresh(n):
     """the same two calls in a FRESH process (what a user's first call costs: HIP runtime bring-up and
     code-object load, hierarchy set-up, first touch of the result pages), as a child process"""
-    import subprocess
     code = ("import sys, json; sys.path.insert(0, %r); import bench, ndsm_amd; L = ndsm_amd.load_library(); "
             "print(json.dumps(bench.end_to_end(L, %d, pretouch=False)))" % (ROOT, n))
     try:
-        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                           timeout=600, cwd=ROOT)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode != 0 or not lines:
-            return {"error": (r.stderr or r.stdout)[-300:]}
+        rc_, out_, err_ = run_child([sys.executable, "-c", code], 600, cwd=ROOT)
+        lines = [l for l in out_.splitlines() if l.startswith("{")]
+        if rc_ != 0 or not lines:
+            return {"error": (err_ or out_)[-300:]}
         j = json.loads(lines[-1])
         return {"first_call_s": j.get("e2e_s"), "second_call_s": j.get("e2e_second_call_s"),
                 "what": "fresh process, A = numpy.zeros (untouched pages, as the reference's ndsm.py passes it): the first "
@@ -249,6 +305,88 @@ def slab_window_problem(n3, sl):
     return [x, y, z], np.ascontiguousarray(rhs), a
 
 
+def baseline_configs(_lib, L, ms, steps):
+    """BASELINE.json configs 0, 1 and 3 on ONE GPU (config[2] is the timed workload itself, config[4] needs the
+    8-GPU node): the manufactured Poisson problem SURVEY 8d names for them - time per solve-loop cycle, cycles
+    to vc_tol = 1e-10, whole-solve time.  Arrays resident in HBM before each timed region."""
+    out = {}
+    for key, n3, ngrids, what in (
+            ("config0", [64, 64, 64], 3, "64^3 Poisson, 3-level V-cycle (BASELINE config[0]; the reference rule gives 5 levels)"),
+            ("config1", [256, 256, 256], 6, "256^3 Poisson fp64, 6-level V-cycle (BASELINE config[1]; the reference rule gives 7)"),
+            ("config3_on_one_gpu", [1024, 1024, 512], 0, "1024x1024x512 Poisson fp64 (BASELINE config[3]'s workload) on one GPU, reference level rule")):
+        try:
+            mesh, rhs, _a = slab_window_problem(n3, {"k0": 0, "nloc": n3[2]})
+            S = _lib.MGSolver(n3, mesh, "NDDNDD", ngrids=ngrids, ms=ms, lib=L)
+            S.upload(1, _lib.BUF_RHS, rhs)
+            del rhs
+            S.solve(vc_tol=0.0, nmax=2)
+            S.sync()
+            t0 = time.perf_counter()
+            S.solve(vc_tol=0.0, nmax=steps)
+            S.sync()
+            cyc_ms = (time.perf_counter() - t0) / steps * 1e3
+            ent = {"what": what, "ms_per_cycle": cyc_ms, "levels": S.ngrids,
+                   "LUPs_per_s": 2 * ms * float(n3[0]) * n3[1] * n3[2] / (cyc_ms * 1e-3)}
+            if key != "config3_on_one_gpu":
+                S.upload(1, _lib.BUF_U, np.zeros(tuple(n3[::-1])))
+                S.sync()
+                t0 = time.perf_counter()
+                ie, du, nc, _h = S.solve(vc_tol=1e-10, nmax=1024)
+                S.sync()
+                ent.update({"cycles_to_tolerance": nc, "solve_s": time.perf_counter() - t0, "du_last": du, "ierr": ie,
+                            "vc_tol": 1e-10})
+            S.close()
+            del S
+            out[key] = ent
+        except Exception as exc:  # noqa: BLE001
+            out[key] = {"what": what, "error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
+def end_to_end_small(L):
+    """ndsm_vector_solve at the sizes the reference's own users run (its integration test: 22^3 ... 220^3,
+    tests/integration_test/results_test1.txt:6-14): wall time of the SECOND call on a mesh (cached context), host
+    buffers in and out, analytic test field, default options."""
+    import ctypes
+    from golden_inputs import analytic_case
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    L.ndsm_vector_solve.argtypes = [ctypes.c_size_t, ip, ip, dp, dp, dp, dp, dp, dp]
+    L.ndsm_vector_solve.restype = ctypes.c_int
+    out = {"what": "ndsm_vector_solve wall time, second call on the same mesh, host buffers in and out, vc_tol=1e-10, ms=5",
+           "reference_published_220_s": 174.0,
+           "reference_published_source": "tests/integration_test/results_test1.txt:14 (hardware and thread count not stated)"}
+    for n in (64, 128, 220):
+        try:
+            x, y, z, _A1, b1 = analytic_case(n)
+            nshape = np.array([n, n, n, 3], dtype=np.intc)
+            A, B = np.empty(b1.size), np.empty(b1.size)
+            best = None
+            for _ in range(3):
+                ioptc = np.zeros(16, dtype=np.intc)
+                ropt = np.zeros(16)
+                ioptc[L.get_iopt_ms()] = 5
+                ioptc[L.get_iopt_ncycles()] = 1024
+                ioptc[L.get_iopt_iopt_nmaxex()] = 10000
+                ioptc[L.get_iopt_dumax()] = 1
+                ropt[L.get_ropt_vtol()] = 1e-10
+                ropt[L.get_ropt_ctol()] = 1e-13
+                A[:] = 0.0
+                B[:] = b1.ravel()
+                t0 = time.perf_counter()
+                ierr = L.ndsm_vector_solve(ctypes.c_size_t(B.size), nshape.ctypes.data_as(ip), ioptc.ctypes.data_as(ip),
+                                           ropt.ctypes.data_as(dp), x.ctypes.data_as(dp), y.ctypes.data_as(dp),
+                                           z.ctypes.data_as(dp), A.ctypes.data_as(dp), B.ctypes.data_as(dp))
+                dt = time.perf_counter() - t0
+                if ierr != 0:
+                    raise RuntimeError(f"ndsm_vector_solve returned {ierr}")
+                if _ > 0:
+                    best = dt if best is None else min(best, dt)
+            out[f"{n}^3_ms"] = best * 1e3
+        except Exception as exc:  # noqa: BLE001
+            out[f"{n}^3_ms"] = f"error: {type(exc).__name__}: {exc}"
+    return out
+
+
 def slab_self_check(_lib, L, dist, rank, world):
     """The distributed path against the single-GPU solver on a problem small enough to gather:
     level 1 of a 128 x 128 x 32N box cut into N z-slabs (RCCL halo exchange, the same code path as
@@ -310,7 +448,13 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-solve / ndsm_vector_solve timings")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="take roofline.traffic from profiles/traffic_latest.json instead of two rocprofv3 --pmc child runs")
+    ap.add_argument("--slab-shape", default="1024,1024,512",
+                    help="N > 1: the grid cut into z-slabs (default: BASELINE config[3]; smaller for rehearsals)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a lone process asked for N GPUs: it becomes the launcher of N ranks (one process per GPU)
+        raise SystemExit(spawn_ranks(args))
 
     # ONE JSON line on stdout: everything else this process and the native libraries under it write to
     # file descriptor 1 (the reference's and our Fortran `PRINT *` warnings, flushed at exit) goes to
@@ -323,11 +467,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        # one process per GPU: the launcher (python -m torch.distributed.run --nproc-per-node N) starts the
-        # ranks; a lone process asked for N GPUs must not report a 1-GPU number as an N-GPU one
+        # one process per GPU: a rank of an M-rank job must not report an N-GPU number
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
-                         f"--master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
+                         f"--master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...` "
+                         f"(or without a launcher: `python3 bench.py --gpus {args.gpus}` starts its own ranks)")
 
     # libndsm_hip FIRST: it loads /opt/rocm's libamdhip64.so.7 / librccl.so.1.  PyTorch bundles a
     # second ROCm stack under the same SONAMEs; whichever is loaded first serves the whole process,
@@ -426,10 +570,18 @@ def main():
                     os.environ.pop("NDSM_HIP_OVERLAP", None)
                 else:
                     os.environ["NDSM_HIP_OVERLAP"] = old
-        bad = [c for c in checks if "MISMATCH" in c]
-        all_ok(not bad, "slab self-check against the single-GPU solver", "; ".join(bad))
-        slab_check = checks[0] + " [exchange on the main stream]; " + (checks[1] or checks[0]) + " [exchange overlapped]"
-        n3 = [1024, 1024, 512]
+        # verdicts are rank 0's (it holds the gathered planes): every rank must act on the same ones
+        verdict = [checks if rank == 0 else None]
+        dist.broadcast_object_list(verdict, 0)
+        checks = verdict[0]
+        all_ok("MISMATCH" not in checks[0], "slab self-check against the single-GPU solver (exchange on the main stream)", checks[0])
+        slab_check = checks[0] + " [exchange on the main stream]; " + checks[1] + " [exchange overlapped]"
+        if "MISMATCH" in checks[1]:
+            # the overlapped schedule (second stream, one communicator) misbehaves on this node but the
+            # single-stream one is right: time THAT - still the z-slab RCCL path - and say so
+            os.environ["NDSM_HIP_OVERLAP"] = "0"
+            slab_check += "; TIMED WITH NDSM_HIP_OVERLAP=0 (single-stream exchange) because the overlapped self-check failed"
+        n3 = [int(v) for v in args.slab_shape.split(",")]
         x = np.linspace(0.0, 1.0, n3[0])
         dx = x[1] - x[0]
         mesh = [x, np.arange(n3[1]) * dx, np.arange(n3[2]) * dx]
@@ -444,11 +596,12 @@ def main():
             S.sync()
         except Exception as exc:  # noqa: BLE001
             err = f"{type(exc).__name__}: {exc}"
-        all_ok(not err, "z-slab world (1024x1024x512)", err)
+        all_ok(not err, f"z-slab world ({n3[0]}x{n3[1]}x{n3[2]})", err)
         run_cycles = lambda k: S.solve(vc_tol=0.0, nmax=k)  # noqa: E731
         ngrids = 8
-        workload = (f"1024x1024x512 Poisson (manufactured right-hand side, zero initial guess: SURVEY 8d), one "
-                    f"V-cycle + convergence metric per step (ms={ms}), config[3] of BASELINE.json")
+        workload = (f"{n3[0]}x{n3[1]}x{n3[2]} Poisson (manufactured right-hand side, zero initial guess: SURVEY 8d), one "
+                    f"V-cycle + convergence metric per step (ms={ms})" +
+                    (", config[3] of BASELINE.json" if n3 == [1024, 1024, 512] else ", REHEARSAL SHAPE (not config[3])"))
         parallelism = (f"level 1 in {world} z-slabs (RCCL send/recv halo: 4 planes per neighbour per two-sweep "
                        f"pass), {S.dist_levels} distributed level(s), the rest on rank 0")
         scaling = "strong"
@@ -558,23 +711,34 @@ def main():
         t_live, src = live_traffic(args.n, True, "rbgs3_fused_k<double,2,136,30,1024,4,true,0,true,false>")
         if t_live:
             traffic, tsrc = t_live, src
+            g_live, gsrc = live_traffic(args.n, False, "rbgs3_fused_k<double,2,136,30,1024,4,false,0,true,false>")
+            if g_live:
+                traffic_gen, tsrc_gen = g_live, gsrc
         else:
             tsrc = (tsrc or "") + f" [live measurement skipped: {src}]"
 
     def roofline(ms_sweep, bytes_per_lup, kernel, tr, src=None):
         launch_s = 2 * ms_sweep * 1e-3
         alg = 2 * bytes_per_lup * npts / world                    # per launch and GPU: two sweeps
-        r = {"bound": "hbm", "achieved": alg / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": alg / launch_s / 1e9 / HBM_PEAK_GBS, "traffic": tr,
-             "kernel": kernel, "bytes_per_lup": bytes_per_lup, "sweeps_per_launch": 2,
-             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": launch_s * 1e3,
-             "frac_algorithmic": alg / launch_s / 1e9 / HBM_PEAK_GBS,
-             "frac_hbm": (tr / launch_s / 1e9 / HBM_PEAK_GBS) if tr else None,
+        # achieved / frac: what the memory system really moved (HBM bytes per launch from the rocprofv3 counters)
+        # over the launch time; null when no counter figure exists for this launch.  The algorithmic figure
+        # stands beside it under its own name: ONE launch performs TWO sweeps on one pass over HBM (temporal
+        # blocking), so bytes_per_lup x 2 sweeps x points / time says how fast the sweeps go, not what HBM did -
+        # SURVEY 8d's 24 B/LUP (u in, rhs in, u out per sweep) does not describe a launch that reads u once for two
+        # sweeps and (Laplace variant) never reads rhs.
+        hbm = (tr / launch_s / 1e9) if tr else None
+        r = {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": (hbm / HBM_PEAK_GBS) if hbm else None, "traffic": tr,
+             "kernel": kernel, "avg_launch_ms": launch_s * 1e3,
              "traffic_source": (src if src is not None else tsrc) if tr else None,
-             "note": "frac = frac_algorithmic = SURVEY 8d algorithmic bytes (bytes_per_lup x 2 sweeps x points) / launch "
-                     "time / 8 TB/s: one launch performs TWO sweeps on one pass over HBM (temporal blocking), so it "
-                     "can exceed what the memory system moves; frac_hbm = HBM bytes the launch really moved "
-                     "(traffic) / launch time / 8 TB/s"}
+             "bytes_per_lup": bytes_per_lup, "sweeps_per_launch": 2, "algorithmic_bytes_per_launch": alg,
+             "achieved_algorithmic": alg / launch_s / 1e9,
+             "frac_algorithmic": alg / launch_s / 1e9 / HBM_PEAK_GBS,
+             "note": "frac = achieved / peak with achieved = HBM bytes the launch really moved (traffic: FETCH_SIZE x 2 + "
+                     "WRITE_SIZE, rocprofv3 --pmc) / average launch time (HIP events on the library stream); "
+                     "frac_algorithmic = bytes_per_lup x 2 sweeps x points / launch time / peak - it exceeds frac because "
+                     "one pass over HBM carries two sweeps" +
+                     ("" if tr else "; NO counter figure for this launch: frac is null, only the algorithmic figure is given")}
         return r
 
     def finish():
@@ -628,9 +792,14 @@ def main():
         out["slab_check"] = slab_check
     if one_gpu_ms:
         out["same_workload_on_one_gpu"] = {"ms_per_step": one_gpu_ms, "speedup": one_gpu_ms / ms_per_step,
-                                           "what": "the identical 1024x1024x512 problem and loop on rank 0's GPU alone, "
+                                           "what": f"the identical {n3[0]}x{n3[1]}x{n3[2]} problem and loop on rank 0's GPU alone, "
                                                    "timed after the N-GPU region (strong-scaling reference)"}
     if world == 1 and not args.no_e2e:
+        out["configs"] = baseline_configs(_lib, L, ms, max(3, min(args.steps, 10)))
+        try:
+            out["end_to_end_small"] = end_to_end_small(L)
+        except Exception as exc:  # noqa: BLE001
+            out["end_to_end_small"] = {"error": f"{type(exc).__name__}: {exc}"}
         try:
             out["end_to_end"] = end_to_end(L, args.n)
             out["end_to_end"]["fresh_process"] = end_to_end_fresh(args.n)

@@ -201,6 +201,8 @@ int ndsmk_fetch_fused_metric(double *h_out2);
 /* pieces of an overlapped z-slab pass: one fused pass over owned planes [z0, z1) only (u -> uout) */
 int ndsmk_fused_window(const ndsmk_grid *g, const double *u, double *uout, const double *rhs, int nsweeps, int z0,
                        int z1, const ndsmk_xfer *px, const double *uc, const double *prev, int accumulate);
+int ndsmk_fused_window_res(const ndsmk_grid *g, const double *u, double *uout, const double *rhs, double *rout, int z0,
+                           int z1);
 int ndsmk_fused_metric_ok(const ndsmk_grid *g);
 int ndsmk_fused_prolong_ok(const ndsmk_grid *g, const double *rhs, int nsweeps);
 /* two streams: 1 = later copies / RCCL calls go to the communication stream, 0 = main stream again;

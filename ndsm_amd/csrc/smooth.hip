@@ -496,6 +496,24 @@ extern "C" int ndsmk_fused_window(const ndsmk_grid *gp, const double *u, double 
   return 0;
 }
 
+// The sweep + residual pass on a window of owned planes [z0, z1): ONE sweep u -> uout and r = rhs - L uout on the
+// window (u must be valid on z0 - 3 .. z1 + 2).  For the pieces of the last pre-smoothing pass whose halo
+// exchange overlaps its interior (ndsmh_world).
+extern "C" int ndsmk_fused_window_res(const ndsmk_grid *gp, const double *u, double *uout, const double *rhs, double *rout,
+                                      int z0, int z1) {
+  NDSM_REQUIRE_READY();
+  ndsmk_grid g = *gp;
+  NDSM_CHECK_ARG(g.ndim == 3 && rout && z0 >= g.zown0 && z1 <= g.zown1 && z0 < z1);
+  g.zown0 = z0;
+  g.zown1 = z1;
+  int ndone = 0, res = 0;
+  int rc = ndsm::launch_rbgs3_fused(g, u, uout, rhs, 1, true, &ndone, rout, &res, nullptr, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  if (ndone != 1 || !res)
+    return ndsm::fail(NDSMK_EARG, "fused sweep + residual: this window is not covered", __FILE__, __LINE__);
+  return 0;
+}
+
 // can ndsmk_fused_window(..., prev) evaluate the metric? (fp64 level off the all-Neumann path)
 extern "C" int ndsmk_fused_metric_ok(const ndsmk_grid *gp) { return (gp->ndim == 3 && !gp->all_neumann) ? 1 : 0; }
 

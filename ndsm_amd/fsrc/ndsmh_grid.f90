@@ -63,6 +63,7 @@ module ndsmh_grid
     integer :: ck0 = 0, ck1 = 0      ! coarse planes this rank computes in the restriction
     integer :: pk0 = 0, pk1 = 0      ! coarse planes this rank reads in the prolongation
     integer :: cb0 = 0, cb1 = 0      ! window of the local coarse buffer = union of the two
+    integer :: ci0 = 0, ci1 = 0      ! the coarse planes of [ck0, ck1) whose taps all lie in owned fine planes
   end type
 
 contains
@@ -101,6 +102,7 @@ contains
         plan(r)%z1 = int((int(r + 1, ik) * nz) / nranks)
       end if
       plan(r)%ck0 = nzc; plan(r)%ck1 = 0
+      plan(r)%ci0 = nzc; plan(r)%ci1 = 0
     end do
     if (present(part)) then
       if (part(0) /= 0 .or. part(nranks) /= nz) return
@@ -117,10 +119,17 @@ contains
       plan(own)%ck0 = min(plan(own)%ck0, kc)
       plan(own)%ck1 = max(plan(own)%ck1, kc + 1)
       depth = max(depth, plan(own)%z0 - lo, hi - plan(own)%z1)
+      if (lo >= plan(own)%z0 .and. hi <= plan(own)%z1) then   ! (tap ranges are monotone: one contiguous run)
+        plan(own)%ci0 = min(plan(own)%ci0, kc)
+        plan(own)%ci1 = max(plan(own)%ci1, kc + 1)
+      end if
     end do
     do r = 0, nranks - 1
       if (plan(r)%ck1 <= plan(r)%ck0) then      ! owns no coarse plane
         plan(r)%ck0 = 0; plan(r)%ck1 = 0
+      end if
+      if (plan(r)%ci1 <= plan(r)%ci0) then
+        plan(r)%ci0 = plan(r)%ck0; plan(r)%ci1 = plan(r)%ck0
       end if
       plan(r)%g = depth
       plan(r)%nloc = plan(r)%z1 - plan(r)%z0 + 2 * depth

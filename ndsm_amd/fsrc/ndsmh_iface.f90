@@ -161,6 +161,14 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_fused_window_res(g, u, uout, rhs, rout, z0, z1) bind(c, name="ndsmk_fused_window_res") result(rc)
+      import :: ndsmk_grid, c_ptr, c_int
+      type(ndsmk_grid), intent(in) :: g
+      type(c_ptr), value :: u, uout, rhs, rout
+      integer(c_int), value :: z0, z1
+      integer(c_int) :: rc
+    end function
+
     function ndsmk_fused_metric_ok(g) bind(c, name="ndsmk_fused_metric_ok") result(ok)
       import :: ndsmk_grid, c_int
       type(ndsmk_grid), intent(in) :: g

@@ -26,7 +26,7 @@ module ndsmh_mg
 
   public :: mg_solver, mg_create, mg_destroy, mg_vcycle, mg_solve
   public :: mg_solve_lanes
-  public :: mg_mixed_applies, mg_relax_window, mg_swap_u, mg_window_prolong_ok, mg_window_metric_ok
+  public :: mg_mixed_applies, mg_relax_window, mg_relax_res_window, mg_swap_u, mg_window_prolong_ok, mg_window_metric_ok
   public :: mg_set_u, mg_set_rhs, mg_get_u, mg_zero_rhs, mg_level_ptr, mg_op, mg_read_info
   public :: mg_mark_rhs_set
   public :: mg_set_bcs, mg_export_u, mg_reset_info, mg_vcycle_from, mg_slab_restrict, mg_slab_prolong
@@ -750,6 +750,14 @@ contains
     end if
   end function
 
+  ! the sweep + residual pass on owned planes [z0, z1) of a slab: u -> ualt, residual of the result -> r
+  function mg_relax_res_window(s, z0, z1) result(rc)
+    type(mg_solver), intent(inout), target :: s
+    integer, intent(in) :: z0, z1
+    integer(c_int) :: rc
+    rc = ndsmk_fused_window_res(s%lev(1)%g, s%dl(1)%u, s%dl(1)%ualt, rhs_of(s, 1), s%r, int(z0, c_int), int(z1, c_int))
+  end function
+
   function mg_window_metric_ok(s) result(ok)
     type(mg_solver), intent(in) :: s
     logical :: ok
@@ -774,23 +782,29 @@ contains
   ! [ck0, ck1) of cbuf (the planes are shipped to rank 0 by the caller)
   ! (dst, dst_k0 given: into that array of whole coarse planes instead, whose plane 0 is global
   ! coarse plane dst_k0 - the rhs slab of the next level when that is distributed as well)
-  function mg_slab_restrict(s, dst, dst_k0) result(rc)
+  ! (ka, kb given: only the coarse planes [ka, kb) of that window - the pieces of a restriction whose
+  ! residual exchange overlaps the planes that do not need it)
+  function mg_slab_restrict(s, dst, dst_k0, ka, kb) result(rc)
     type(mg_solver), intent(inout) :: s
     type(c_ptr), intent(in), optional :: dst
-    integer, intent(in), optional :: dst_k0
+    integer, intent(in), optional :: dst_k0, ka, kb
     integer(c_int) :: rc
     type(ndsmk_xfer) :: x
+    integer :: k0, k1
     rc = 0
-    if (s%sl%ck1 <= s%sl%ck0) return
+    k0 = s%sl%ck0; k1 = s%sl%ck1
+    if (present(ka)) k0 = max(k0, ka)
+    if (present(kb)) k1 = min(k1, kb)
+    if (k1 <= k0) return
     x = s%xf(1)%x
-    x%c_cnt = s%sl%ck1 - s%sl%ck0
+    x%c_cnt = k1 - k0
     if (present(dst)) then
       x%c_k0 = dst_k0
-      x%c_beg = s%sl%ck0 - dst_k0
+      x%c_beg = k0 - dst_k0
       rc = ndsmk_restrict(x, s%r, dst, c_null_ptr)
     else
       x%c_k0 = s%sl%cb0
-      x%c_beg = s%sl%ck0 - s%sl%cb0
+      x%c_beg = k0 - s%sl%cb0
       rc = ndsmk_restrict(x, s%r, s%cbuf, c_null_ptr)
     end if
   end function

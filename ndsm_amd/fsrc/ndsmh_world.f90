@@ -607,7 +607,29 @@ contains
       end if
       mt = 0
       if (domet) mt = 1
-      if (res .and. left == 1) then
+      if (res .and. left == 1 .and. w%ghost_depth < 3 .and. overlap_ok(w, 3)) then
+        ! the sweep + residual pass in three pieces as well: its exchange (3 planes: one more for the
+        ! residual's stencil) on the communication stream behind the planes that do not need it
+        d = 3
+        rc = ndsmk_stream_fence(0_c_int, 1_c_int); if (rc /= 0) return
+        rc = ndsmk_select_stream(1_c_int); if (rc /= 0) return
+        rc = exchange(w, MG_BUF_U, d)
+        i = ndsmk_select_stream(0_c_int)
+        if (rc /= 0) return
+        do i = 1, w%nlocal
+          associate (s => w%loc(i))
+            rc = mg_relax_res_window(s, int(s%lev(1)%g%zown0) + d, int(s%lev(1)%g%zown1) - d); if (rc /= 0) return
+          end associate
+        end do
+        rc = ndsmk_stream_fence(1_c_int, 0_c_int); if (rc /= 0) return
+        do i = 1, w%nlocal
+          associate (s => w%loc(i))
+            rc = mg_relax_res_window(s, int(s%lev(1)%g%zown0), int(s%lev(1)%g%zown0) + d); if (rc /= 0) return
+            rc = mg_relax_res_window(s, int(s%lev(1)%g%zown1) - d, int(s%lev(1)%g%zown1)); if (rc /= 0) return
+            call mg_swap_u(s)
+          end associate
+        end do
+      else if (res .and. left == 1) then
         rc = need_ghosts(w, 3); if (rc /= 0) return
         do i = 1, w%nlocal
           rc = mg_op(w%loc(i), MG_OP_RELAX_RES_FUSED, 1, 1); if (rc /= 0) return
@@ -690,6 +712,7 @@ contains
     type(mg_world), intent(inout) :: w
     integer(c_int) :: rc
     integer :: i
+    logical :: split
     if (.not. allocated(w%psrc)) allocate (w%psrc(w%nlocal), w%psk0(w%nlocal), w%psn(w%nlocal))
 
     ! ---- level 1, downwards (fine_to_coarse, ndsm_multigrid_core.f90:482-560)
@@ -702,15 +725,42 @@ contains
         rc = mg_op(w%loc(i), MG_OP_RESIDUAL, 1, 1); if (rc /= 0) return
       end do
     end if
-    rc = exchange(w, MG_BUF_R, w%plan(0)%g); if (rc /= 0) return
+    ! the residual crosses the slab cuts (the restriction of a rank's first and last coarse planes reads up to g
+    ! fine planes of its neighbours) - behind the restriction of the coarse planes that do not need it where the
+    ! message is worth it (split = .true.: those planes are restricted below, the others after the fence)
+    split = overlap_ok(w, w%plan(0)%g)
+    do i = 1, w%nlocal
+      split = split .and. w%loc(i)%sl%ci1 - w%loc(i)%sl%ci0 >= 8
+    end do
+    if (split) then
+      rc = ndsmk_stream_fence(0_c_int, 1_c_int); if (rc /= 0) return
+      rc = ndsmk_select_stream(1_c_int); if (rc /= 0) return
+      rc = exchange(w, MG_BUF_R, w%plan(0)%g)
+      i = ndsmk_select_stream(0_c_int)
+      if (rc /= 0) return
+    else
+      rc = exchange(w, MG_BUF_R, w%plan(0)%g); if (rc /= 0) return
+    end if
     if (associated(w%child)) then
       ! ---- the next level is distributed as well: every rank restricts its coarse planes straight
       ! into its own slab of the child's right-hand side, the child runs its part of the cycle
       ! (V-cycle from its level + the sweeps that precede an interpolation, :642-644), and the
       ! correction is interpolated from the child's own slab (its ghosts made current first)
       associate (c => w%child)
+        if (split) then
+          do i = 1, w%nlocal
+            rc = mg_slab_restrict(w%loc(i), c%loc(i)%dl(1)%rhs, c%loc(i)%sl%k0, w%loc(i)%sl%ci0, w%loc(i)%sl%ci1)
+            if (rc /= 0) return
+          end do
+          rc = ndsmk_stream_fence(1_c_int, 0_c_int); if (rc /= 0) return
+        end if
         do i = 1, w%nlocal
-          rc = mg_slab_restrict(w%loc(i), c%loc(i)%dl(1)%rhs, c%loc(i)%sl%k0); if (rc /= 0) return
+          if (split) then
+            rc = mg_slab_restrict(w%loc(i), c%loc(i)%dl(1)%rhs, c%loc(i)%sl%k0, kb=w%loc(i)%sl%ci0); if (rc /= 0) return
+            rc = mg_slab_restrict(w%loc(i), c%loc(i)%dl(1)%rhs, c%loc(i)%sl%k0, ka=w%loc(i)%sl%ci1); if (rc /= 0) return
+          else
+            rc = mg_slab_restrict(w%loc(i), c%loc(i)%dl(1)%rhs, c%loc(i)%sl%k0); if (rc /= 0) return
+          end if
           rc = ndsmk_fill0(c%loc(i)%dl(1)%u, int(c%loc(i)%npts1, c_size_t) * R8)   ! :557-558
           if (rc /= 0) return
           call mg_mark_rhs_set(c%loc(i))
@@ -726,9 +776,20 @@ contains
         end do
       end associate
     else
-      do i = 1, w%nlocal
-        rc = mg_slab_restrict(w%loc(i)); if (rc /= 0) return
-      end do
+      if (split) then
+        do i = 1, w%nlocal
+          rc = mg_slab_restrict(w%loc(i), ka=w%loc(i)%sl%ci0, kb=w%loc(i)%sl%ci1); if (rc /= 0) return
+        end do
+        rc = ndsmk_stream_fence(1_c_int, 0_c_int); if (rc /= 0) return
+        do i = 1, w%nlocal
+          rc = mg_slab_restrict(w%loc(i), kb=w%loc(i)%sl%ci0); if (rc /= 0) return
+          rc = mg_slab_restrict(w%loc(i), ka=w%loc(i)%sl%ci1); if (rc /= 0) return
+        end do
+      else
+        do i = 1, w%nlocal
+          rc = mg_slab_restrict(w%loc(i)); if (rc /= 0) return
+        end do
+      end if
       rc = gather_coarse(w); if (rc /= 0) return
 
       ! ---- levels >= 2 on rank 0 ------------------------------------------

@@ -187,3 +187,26 @@ def test_bench_two_ranks_rehearsal(hip):
     assert "fake_rccl" in out["rocm_stack"]["rccl"]
     one = out["same_workload_on_one_gpu"]               # both ranks share this GPU: the split cannot be faster
     assert one["ms_per_step"] > 0 and 0.2 < one["speedup"] < 1.3, one
+
+
+def test_bench_lone_process_starts_its_own_ranks(hip):
+    """`python3 bench.py --gpus N` WITHOUT a launcher (the form of the driver's N = 1 command): the process starts
+    its own N ranks before touching the GPU, relays rank 0's line and exits with the launcher's code.  Four ranks
+    at a reduced shape - two distributed levels, 48-plane slabs - on this box's one GPU over the test double
+    (the pool's process guard allows six GPU processes on a box, this test process being one of them: an
+    eight-process rehearsal cannot run here; the N = 8 plan itself - 64-plane slabs, two distributed levels -
+    runs as eight loop-back slabs in test_gpu_parity.py::test_full_size_config4_loopback)."""
+    env = dict(os.environ, NDSM_HIP_LIB=_fake(), FAKE_RCCL_TIMEOUT="120", FAKE_RCCL_SLOT_MB="64")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+           "--slab-shape", "256,256,192", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["slab_mode"] is True and out["rccl_ranks"] == 4
+    assert "MISMATCH" not in out["slab_check"], out["slab_check"]
+    assert "REHEARSAL SHAPE" in out["config"]["workload"]
+    assert out["roofline"]["frac"] is None and out["roofline"]["frac_algorithmic"] > 0     # no counter figure in slab mode
