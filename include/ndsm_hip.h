@@ -255,9 +255,6 @@ int ndsm_hip_bound_libs(char *buf, int len);
  * parity tests can run the benchmarked 512^3 configurations on grids the oracle handles.
  * Results never depend on these values (bit for bit); only speed does. */
 int ndsm_hip_debug_fused_cfg(int two, int one, int res, int work_items, int big);
-/* Levels of 4097 ... max_points points take the LDS-tile smoother (csrc/smooth_tile.hip: S sweeps per launch
- * on 3-D tiles); 0 = none (default; environment NDSM_TILE_MAX sets the initial value).  Same bits either way. */
-int ndsm_hip_debug_tile_max(long long max_points);
 /* 0: the small levels at the bottom of a V-cycle run kernel by kernel even where the single-launch form
  * (csrc/tail.hip: all of them resident in LDS, one workgroup) covers them; 1 = default (environment
  * NDSM_HIP_NO_TAIL switches it off for a whole process).  Same bits either way. */

@@ -114,7 +114,7 @@ def _f64(a):
 
 # ops / buffers of ndsm_hip_mg_op, ndsm_hip_mg_upload (ndsmh_mg.f90)
 BUF_U, BUF_RHS, BUF_R = 0, 1, 2
-OP_RELAX, OP_RESIDUAL, OP_RESTRICT, OP_PROLONG, OP_EXACT, OP_RELAX_COLOR, OP_RELAX_FUSED, OP_RESREST, OP_RELAX_RES, OP_RELAX_RES_FUSED = range(10)
+OP_RELAX, OP_RESIDUAL, OP_RESTRICT, OP_PROLONG, OP_EXACT, OP_RELAX_COLOR, OP_RELAX_FUSED, _OP_RETIRED_7, OP_RELAX_RES, OP_RELAX_RES_FUSED = range(10)
 
 
 class MGSolver:

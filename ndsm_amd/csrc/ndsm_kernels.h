@@ -128,12 +128,6 @@ int ndsmk_residual(const ndsmk_grid *g, const double *u, const double *rhs, doub
 int ndsmk_restrict(const ndsmk_xfer *x, const double *r_f, double *rhs_c, double *u_c);
 /* footprint of the LDS-streamed restriction, for the host-side coverage check */
 void ndsmk_restrict_stream_tile(int *ci, int *cj, int *fx, int *fy, int *maxt);
-/* fused residual + restriction (resrest.hip): rhs_c = R (rhs - L u), u_c = 0, the
- * residual never leaves the chip.  Only where ndsmk_resrest_tile's footprint
- * covers every coarse tile's taps (checked by the host driver). */
-void ndsmk_resrest_tile(int *ci, int *cj, int *ux, int *uy, int *maxt);
-int ndsmk_residual_restrict(const ndsmk_grid *g, const ndsmk_xfer *x, const double *u, const double *rhs,
-                            double *rhs_c, double *u_c);
 /* u_f += P u_c (ndsm_multigrid_core.f90:659,672) */
 int ndsmk_prolong_add(const ndsmk_xfer *x, const double *u_c, double *u_f);
 /* blocking: out[0] = max|a-b|, out[1] = sum|a-b| ; then b <- a if copy != 0
@@ -231,7 +225,6 @@ int ndsmk_prolong_add_f32(const ndsmk_xfer *x, const double *u_c, float *e_f);
 
 /* tests / tuning: the five values of NDSM_FUSED_CFG (smooth_fused.hip) at run time */
 int ndsmk_debug_fused_cfg(int two, int one, int res, int work_items, int big);
-int ndsmk_debug_tile_max(long long max_points);   /* smooth_tile.hip: levels of up to that many points use it (0 none) */
 
 #ifdef __cplusplus
 }

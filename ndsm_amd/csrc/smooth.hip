@@ -20,9 +20,6 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
                        const ndsmk_xfer *px, const double *uc);
 int fetch_fused_metric(double *h_out2);
 int launch_mean_shift(double *u, int64_t n);
-bool tile_smoother_applies(const ndsmk_grid &g);
-int launch_rbgs3_tile(const ndsmk_grid &g, const double *u, double *uout, const double *rhs, int max_sweeps, int *done,
-                      double *rout, int *res_done);
 }
 
 namespace {
@@ -288,35 +285,7 @@ static int relax_impl(const ndsmk_grid *gp, double *const bufs[3], const double 
     NDSM_LAUNCH_CHECK();
     return 0;
   }
-  // mid-size 3-D level: S sweeps per launch on LDS-resident 3-D tiles, out of place (smooth_tile.hip);
-  // the residual rides on the last launch
-  if (g.ndim == 3 && variant == 0 && nsweeps > 0 && !keep && !prev && bufs[1] && ndsm::tile_smoother_applies(g)) {
-    if (prol_pending) {
-      if (int rc = ndsmk_prolong_add(px, uc, bufs[0])) return rc;
-    }
-    int left = nsweeps;
-    while (left > 0) {
-      int dst = -1;
-      for (int c = 0; c < 3; ++c)
-        if (c != cur && bufs[c]) {
-          dst = c;
-          break;
-        }
-      int done = 0;
-      if (int rc = ndsm::launch_rbgs3_tile(g, bufs[cur], bufs[dst], rhs, left, &done, rout, res_done)) return rc;
-      cur = dst;
-      left -= done;
-    }
-    if (cur != 0) {
-      if (where) {
-        *where = cur;
-      } else {
-        NDSM_HIP(hipMemcpyAsync(bufs[0], bufs[cur], sizeof(double) * (size_t)npts, hipMemcpyDeviceToDevice, s));
-      }
-    }
-    return 0;
-  }
-  // mid-size 2-D level: likewise, u in (dynamic) LDS only
+  // mid-size 2-D level: the same single-workgroup scheme, u in (dynamic) LDS only
   if (g.ndim == 2 && variant == 0 && npts <= kMed2D && nsweeps > 0) {
     NDSM_CHECK_ARG(in_place_ok());
     if (prol_pending) {

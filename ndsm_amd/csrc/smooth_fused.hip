@@ -963,18 +963,21 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
                            (MODE == 3 ? sizeof(double) * (2 * (TXH / 2 + 3) * (TYH / 2 + 3) + 2 * TXH + 2 * TYH) : 0);
   static int attr_epoch[2] = {0, 0};   // per instantiation and device epoch (ndsmk_init may re-target)
   static int wgs_per_cu[2] = {1, 1};
+  // The correction mode exists for the declared-zero right-hand side only: with a right-hand-side window on top of
+  // the interpolation state the kernel does not fit 128 registers (round 3, weights already in LDS: 124 bytes of
+  // scratch per lane), and a Poisson cycle is faster with the stand-alone interpolation in front.
+  constexpr bool GEN = MODE != 3;   // is there an instantiation that reads rhs?
+  if (!GEN && rhs) return ndsm::fail(NDSMK_EARG, "the correction launch is built for rhs == 0 only", __FILE__, __LINE__);
+  using KF = void (*)(const T *, T *, const T *, T *, const T *, double *, ndsmk_grid, FusedPlan, ProlArgs);
+  KF kgen = nullptr;
+  if constexpr (GEN) kgen = rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1, ODD>;
+  const KF kfn = rhs ? kgen : rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1, ODD>;
   const int v = rhs ? 0 : 1;
-  const void *kptr = rhs ? reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1, ODD>)
-                         : reinterpret_cast<const void *>(rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1, ODD>);
+  const void *kptr = reinterpret_cast<const void *>(kfn);
   if (ndsm::first_in_epoch(attr_epoch[v])) {
     NDSM_HIP(hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int occ = 1;
-    if (rhs)
-      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1, ODD>, NT,
-                                                            lds_bytes));
-    else
-      NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1, ODD>, NT,
-                                                            lds_bytes));
+    NDSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, NT, lds_bytes));
     wgs_per_cu[v] = occ > 0 ? occ : 1;
   }
   // z chunks.  A workgroup walks its chunk plus NST warm-up planes on either side, and
@@ -1012,14 +1015,10 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
   if (MODE == 2) {
     if (int rc = met_scratch((size_t)nblk, &part, &out2)) return rc;
   }
-  if (rhs)
-    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, false, MODE, LVL1, ODD>), dim3(nblk), dim3(NT), lds_bytes,
-                       ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl, pa);
-  else  // the level's rhs is identically zero (level 1 of NDSM's Laplace problems,
-        // ndsm_vector_potential.f90:640-641): x - 0.0 == x exactly, so the variant that never
-        // loads rhs returns the same bits with 8 B/LUP less traffic
-    hipLaunchKernelGGL((rbgs3_fused_k<T, S, TXH, TYH, NT, WPS, true, MODE, LVL1, ODD>), dim3(nblk), dim3(NT), lds_bytes,
-                       ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl, pa);
+  // (rhs == nullptr: the level's rhs is identically zero - level 1 of NDSM's Laplace problems,
+  // ndsm_vector_potential.f90:640-641 -; x - 0.0 == x exactly, so the variant that never loads rhs returns the
+  // same bits with 8 B/LUP less traffic)
+  hipLaunchKernelGGL(kfn, dim3(nblk), dim3(NT), lds_bytes, ndsm::stream(), u, uout, rhs, rout, prev, part, g, pl, pa);
   NDSM_LAUNCH_CHECK();
   if (MODE == 2) {
     hipLaunchKernelGGL(fold_metric_k, dim3(1), dim3(256), 0, ndsm::stream(), part, nblk, out2, g_met_acc ? 1 : 0);
@@ -1091,9 +1090,7 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   // (*sweeps_done = 0) and the caller interpolates with the stand-alone kernel first.
   if (prol) {
     if constexpr (std::is_same<T, double>::value) {
-      // (the general-rhs instantiation exists but is never launched: its rhs window on top of the
-      // interpolation state needs 128 VGPRs + 148 B of scratch per lane, and measured at 512^3 a Poisson
-      // cycle takes 7.92 ms with it against 7.25 ms with the stand-alone interpolation kernel in front)
+      // (Laplace problems only - launch_cfg)
       if (!rhs && two && !(met && max_sweeps == 2) && cfg[0] == 0) {
         rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 3, false, ODD>(g, u, uout, rhs, tgt, nullptr, nullptr, prol));
         if (rc) return rc;
@@ -1153,10 +1150,7 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
     if constexpr (ODD) {
       rc = (launch_cfg<T, 1, 136, 22, 768, 4, 1, false, true>(g, u, uout, rhs, tgt, rout));
     } else {
-      switch (cfg[2]) {
-        case 1: rc = (launch_cfg<T, 1, 136, 30, 1024, 4, 1>(g, u, uout, rhs, tgt, rout)); break;
-        default: rc = (launch_cfg<T, 1, 136, 22, 768, 4, 1>(g, u, uout, rhs, tgt, rout)); break;
-      }
+      rc = (launch_cfg<T, 1, 136, 22, 768, 4, 1>(g, u, uout, rhs, tgt, rout));
     }
     if (rc) return rc;
     *sweeps_done = 1;

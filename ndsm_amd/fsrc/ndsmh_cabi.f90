@@ -933,21 +933,6 @@ contains
     rc = ndsmk_debug_fused_cfg(two, one, res, work_items, big)
   end function
 
-  ! development hook: mid-size 3-D levels of up to max_points points take the LDS-tile smoother
-  ! (smooth_tile.hip; 0 = none, the default)
-  function ndsm_hip_debug_tile_max(max_points) bind(c, name="ndsm_hip_debug_tile_max") result(rc)
-    integer(c_long_long), value :: max_points
-    integer(c_int) :: rc
-    interface
-      function ndsmk_debug_tile_max(max_points) bind(c, name="ndsmk_debug_tile_max") result(rc)
-        import :: c_int, c_long_long
-        integer(c_long_long), value :: max_points
-        integer(c_int) :: rc
-      end function
-    end interface
-    rc = ndsmk_debug_tile_max(max_points)
-  end function
-
   ! development hook: 0 = the levels of the V-cycle's tail run kernel by kernel even where the single-launch
   ! form (tail.hip) covers them, 1 = default
   function ndsm_hip_debug_tail(on) bind(c, name="ndsm_hip_debug_tail") result(rc)

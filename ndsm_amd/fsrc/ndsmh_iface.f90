@@ -309,19 +309,6 @@ module ndsmh_iface
       integer(c_int), intent(out) :: ci, cj, fx, fy, maxt
     end subroutine
 
-    subroutine ndsmk_resrest_tile(ci, cj, ux, uy, maxt) bind(c, name="ndsmk_resrest_tile")
-      import :: c_int
-      integer(c_int), intent(out) :: ci, cj, ux, uy, maxt
-    end subroutine
-
-    function ndsmk_residual_restrict(g, x, u, rhs, rhs_c, u_c) bind(c, name="ndsmk_residual_restrict") result(rc)
-      import :: ndsmk_grid, ndsmk_xfer, c_ptr, c_int
-      type(ndsmk_grid), intent(in) :: g
-      type(ndsmk_xfer), intent(in) :: x
-      type(c_ptr), value :: u, rhs, rhs_c, u_c
-      integer(c_int) :: rc
-    end function
-
     function ndsmk_prolong_add(x, u_c, u_f) bind(c, name="ndsmk_prolong_add") result(rc)
       import :: ndsmk_xfer, c_ptr, c_int
       type(ndsmk_xfer), intent(in) :: x

@@ -52,7 +52,6 @@ module ndsmh_mg
   type :: dev_xfer
     type(ndsmk_xfer) :: x
     type(c_ptr) :: blob = c_null_ptr
-    logical :: fused_rr = .false.   ! the fused residual+restriction kernel covers this level pair
   end type
 
   type :: mg_solver
@@ -71,7 +70,6 @@ module ndsmh_mg
     integer(ik) :: vcycles_done = 0
     integer(ik) :: npts1 = 0             ! elements of the level-1 device arrays (local window if z-slab)
     logical :: rhs1_zero = .false.        ! level-1 rhs is identically zero: kernels skip reading it
-    logical :: allow_fused_rr = .false.  ! resrest.hip is correct but not yet faster than residual + streamed restriction
     ! ---- convergence metric without a pass of its own (mg_solve, level 1 on the fused smoother):
     ! the buffer holding the iterate a V-cycle starts from is kept untouched (u, ualt and prev
     ! rotate), and the launch of the cycle's last sweep evaluates max / sum |u_new - u_start|
@@ -224,7 +222,6 @@ contains
       o_rcnt(d) = total; total = total + pad8(int(t(d)%nc, c_size_t) * I4)
     end do
     rc = ndsmk_alloc(s%xf(l)%blob, total); if (rc /= 0) return
-    s%xf(l)%fused_rr = fused_rr_applies(s, l, t)
     s%xf(l)%x%stream_ok = stream_restrict_applies(s, l, t)
 
     s%xf(l)%x%nf = s%lev(l)%n
@@ -317,38 +314,6 @@ contains
       end do
       if (sched) ok = ok + 4
     end block
-  end function
-
-  ! Does resrest.hip cover the transfer l -> l+1?  3-D, even nx, a level large
-  ! enough to fill the chip, at most `maxt` taps per dimension, and - the grids
-  ! being non-nested - the fine taps of every coarse tile inside the tile's
-  ! loaded footprint.
-  function fused_rr_applies(s, l, t) result(ok)
-    type(mg_solver), intent(in) :: s
-    integer, intent(in) :: l
-    type(axis_xfer_t), intent(in) :: t(3)
-    logical :: ok
-    integer(c_int) :: ci, cj, ux, uy, mt
-    integer :: a0, a1, f0, nt, k
-    ok = .false.
-    if (s%ndim /= 3) return
-    if (mod(s%lev(l)%n(1), 2) /= 0) return
-    if (s%lev(l)%npts < 6_ik * 1024_ik * 1024_ik) return
-    call ndsmk_resrest_tile(ci, cj, ux, uy, mt)
-    if (any([t(1)%maxt, t(2)%maxt, t(3)%maxt] > mt)) return
-    nt = (t(1)%nc + ci - 1) / ci
-    do k = 0, nt - 1
-      a0 = k * ci + 1; a1 = min(a0 + ci - 1, int(t(1)%nc))
-      f0 = iand(t(1)%rlo(a0) - 1, not(1))
-      if (t(1)%rlo(a1) + t(1)%rcnt(a1) - 1 > f0 + ux - 2) return
-    end do
-    nt = (t(2)%nc + cj - 1) / cj
-    do k = 0, nt - 1
-      a0 = k * cj + 1; a1 = min(a0 + cj - 1, int(t(2)%nc))
-      f0 = t(2)%rlo(a0) - 1
-      if (t(2)%rlo(a1) + t(2)%rcnt(a1) - 1 > f0 + uy - 2) return
-    end do
-    ok = .true.
   end function
 
   ! Re-target an existing hierarchy at another set of boundary letters: only the
@@ -562,11 +527,8 @@ contains
     case (MG_OP_RESTRICT)       ! r(level) -> rhs(level+1), u(level+1) = 0
       if (level >= s%ngrids) return
       rc = ndsmk_restrict(s%xf(level)%x, s%r, s%dl(level + 1)%rhs, s%dl(level + 1)%u)
-    case (MG_OP_RESREST)        ! fused residual + restrict (error if the level pair is not covered)
-      if (level >= s%ngrids) return
-      if (.not. s%xf(level)%fused_rr) return
-      rc = ndsmk_residual_restrict(s%lev(level)%g, s%xf(level)%x, s%dl(level)%u, s%dl(level)%rhs, &
-                                   s%dl(level + 1)%rhs, s%dl(level + 1)%u)
+    case (MG_OP_RESREST)        ! (retired: the fused residual + restriction kernel was slower than sweep + residual
+      return                    !  in one launch followed by the streamed restriction; the slot keeps its number)
     case (MG_OP_PROLONG)        ! u(level) += P u(level+1)
       if (level >= s%ngrids) return
       rc = ndsmk_prolong_add(s%xf(level)%x, s%dl(level + 1)%u, s%dl(level)%u)
@@ -628,14 +590,8 @@ contains
 
     ! descend: pre-smooth, residual, restrict (fine_to_coarse, :482-560)
     do l = ltop, min(lt, s%ngrids) - 1
-      if (s%xf(l)%fused_rr .and. .not. (s%slab .and. l == 1) .and. s%allow_fused_rr) then
-        rc = mg_op(s, MG_OP_RELAX, l, s%ms); if (rc /= 0) return
-        rc = ndsmk_residual_restrict(s%lev(l)%g, s%xf(l)%x, s%dl(l)%u, s%dl(l)%rhs, s%dl(l + 1)%rhs, s%dl(l + 1)%u)
-        if (rc /= 0) return
-      else
-        rc = mg_op(s, MG_OP_RELAX_RES, l, s%ms); if (rc /= 0) return
-        rc = mg_op(s, MG_OP_RESTRICT, l, 1); if (rc /= 0) return
-      end if
+      rc = mg_op(s, MG_OP_RELAX_RES, l, s%ms); if (rc /= 0) return
+      rc = mg_op(s, MG_OP_RESTRICT, l, 1); if (rc /= 0) return
     end do
 
     ! coarsest grid: iterate the smoother to ex_tol (solve_exact, :728-800)

@@ -154,8 +154,6 @@ def test_additive_entry_points_fail_cleanly_without_a_gpu(lib):
     assert lib.ndsm_hip_dist_selftest(16) != 0                  # no runtime, no communicator
     assert lib.ndsm_hip_shutdown() == 0 and lib.ndsm_hip_shutdown() == 0
     assert lib.ndsm_hip_debug_fused_cfg(0, 0, 0, 0, -1) == 0
-    lib.ndsm_hip_debug_tile_max.argtypes = [ctypes.c_longlong]
-    assert lib.ndsm_hip_debug_tile_max(0) == 0
     assert lib.ndsm_hip_debug_tail(1) == 0
     p = ctypes.c_void_p()
     lib.ndsm_hip_device_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]

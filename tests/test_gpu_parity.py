@@ -134,12 +134,6 @@ def test_large_level_kernels_bitwise(hip, port, ns):
     rc = port.restrict(r, ns, mesh, 1)
     assert np.array_equal(S.download(2, hip.BUF_RHS), rc)
     assert not S.download(2, hip.BUF_U).any()
-    S.upload(2, hip.BUF_RHS, np.zeros_like(rc))
-    try:
-        S.op(hip.OP_RESREST, 1)                        # fused variant, where the tile covers the taps
-        assert np.array_equal(S.download(2, hip.BUF_RHS), rc)
-    except hip.NdsmHipError:
-        pass
     S.upload(2, hip.BUF_U, c)
     S.op(hip.OP_PROLONG, 1)
     assert np.array_equal(S.download(1, hip.BUF_U), want + port.interp(c, ns, mesh, 1))
@@ -1363,54 +1357,6 @@ def test_vecpot_context_reuse_and_cache(hip, port):
     assert np.abs(ref[0][1] - A2).max() <= 1e-12 * np.abs(A2).max()
     h = x[1] - x[0]
     assert np.abs(ref[0][2] - B2).max() <= 1e-12 * np.abs(A2).max() * 4 / h
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("ns", ([64, 64, 64], [33, 22, 27], [40, 24, 32], [100, 37, 51], [128, 128, 128]), ids=_tag)
-def test_tile_smoother_bitwise(hip, port, ns):
-    """the LDS-tile smoother for mid-size levels (smooth_tile.hip; off by default, switched on through the
-    development hook): 1, 2 and 5 sweeps and the sweeps + residual launch against the colour passes and the
-    stand-alone residual, every BC set, general and zero rhs; one case against the oracle"""
-    L = hip.load_library()
-    L.ndsm_hip_debug_tile_max.argtypes = [ctypes.c_longlong]
-    mesh = uniform_mesh(ns)
-    shp = tuple(ns[::-1])
-    u, rhs = rand_field(shp, 2112), rand_field(shp, 2113)
-    try:
-        for bcs in ("NDDNDD", "DNDDND", "DDNDDN", "NNNNND", "DDDDDD"):
-            S = hip.MGSolver(ns, mesh, bcs)
-            for lap in (False, True):
-                if lap:
-                    S.zero_rhs()
-                else:
-                    S.upload(1, hip.BUF_RHS, rhs)
-                for nsw in (1, 2, 5):
-                    L.ndsm_hip_debug_tile_max(0)
-                    S.upload(1, hip.BUF_U, u)
-                    S.op(hip.OP_RELAX_COLOR, 1, nsw)
-                    S.op(hip.OP_RESIDUAL, 1)
-                    uw, rw = S.download(1, hip.BUF_U), S.download(1, hip.BUF_R)
-                    L.ndsm_hip_debug_tile_max(1 << 40)
-                    S.upload(1, hip.BUF_U, u)
-                    S.op(hip.OP_RELAX, 1, nsw)
-                    assert np.array_equal(S.download(1, hip.BUF_U), uw), (bcs, lap, nsw)
-                    S.upload(1, hip.BUF_U, u)
-                    S.upload(1, hip.BUF_R, np.full(shp, np.nan))
-                    S.op(hip.OP_RELAX_RES, 1, nsw)
-                    assert np.array_equal(S.download(1, hip.BUF_U), uw), (bcs, lap, nsw)
-                    assert np.array_equal(S.download(1, hip.BUF_R), rw), (bcs, lap, nsw)
-            S.close()
-        want = u
-        for _ in range(5):
-            want = port.relax3d(want, rhs, mesh, "NDDNDD")
-        S = hip.MGSolver(ns, mesh, "NDDNDD")
-        S.upload(1, hip.BUF_U, u)
-        S.upload(1, hip.BUF_RHS, rhs)
-        S.op(hip.OP_RELAX, 1, 5)
-        assert np.array_equal(S.download(1, hip.BUF_U), want)
-        S.close()
-    finally:
-        L.ndsm_hip_debug_tile_max(0)
 
 
 @pytest.mark.gpu
