@@ -130,3 +130,9 @@ int launch_solve_exact_device(const ndsmk_grid &g, double *u, const double *rhs,
 }
 
 }  // namespace ndsm
+
+// does the coarsest-grid solve of this level run as ONE device launch (no host loop, no read-backs)?
+extern "C" int ndsmk_solve_exact_on_device(const ndsmk_grid *gp) {
+  const int64_t n = (int64_t)gp->n[0] * gp->n[1] * gp->n[2];
+  return (n <= kMaxPts && gp->k0 == 0 && gp->nzg == gp->n[2]) ? 1 : 0;
+}

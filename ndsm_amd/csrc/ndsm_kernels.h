@@ -143,6 +143,7 @@ int ndsmk_diff_metrics_end(double *h_out2);
  * for grids of <= 2048 points.  scratch: n doubles (device). */
 int ndsmk_solve_exact(const ndsmk_grid *g, double *u, const double *rhs, double *scratch,
                       double ex_tol, int use_max, int nmax, int64_t *d_info);
+int ndsmk_solve_exact_on_device(const ndsmk_grid *g);   /* 1: that solve is one launch, nothing comes back to the host */
 
 /* The bottom of a V-cycle as ONE single-workgroup launch (tail.hip): levels g[0..nlev-1] (g[nlev-1] the
  * coarsest grid, x[q] the transfer g[q] -> g[q+1], u[q] / rhs[q] their DEVICE arrays), all resident in LDS:

@@ -335,6 +335,12 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_solve_exact_on_device(g) bind(c, name="ndsmk_solve_exact_on_device") result(ok)
+      import :: ndsmk_grid, c_int
+      type(ndsmk_grid), intent(in) :: g
+      integer(c_int) :: ok
+    end function
+
     function ndsmk_tail_applies(nlev, g, x) bind(c, name="ndsmk_tail_applies") result(ok)
       import :: ndsmk_grid, ndsmk_xfer, c_int
       integer(c_int), value :: nlev

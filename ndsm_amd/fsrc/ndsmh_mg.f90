@@ -329,6 +329,10 @@ contains
     do d = 1, 2 * s%ndim
       if (bcs(d) /= 'D' .and. bcs(d) /= 'N') return
     end do
+    if (all(s%bcs(1:2 * s%ndim) == bcs(1:2 * s%ndim))) then    ! nothing changes (a recorded cycle stays valid)
+      rc = 0
+      return
+    end if
     s%bcs = 'N'
     s%bcs(1:2 * s%ndim) = bcs(1:2 * s%ndim)
     do l = 1, s%ngrids
@@ -348,6 +352,32 @@ contains
     end if
     s%graph = c_null_ptr
   end subroutine
+
+  ! May a solve-loop cycle of this solver (mg_vcycle + metric pass, as mg_solve_lanes enqueues it) be RECORDED
+  ! and replayed as one graph launch?  Decided before anything is recorded:
+  !   * nothing in the cycle may come back to the host: the coarsest grid is solved inside the tail launch or by
+  !     the single-workgroup kernel, not by the host-driven fall-back loop (a copy + synchronise on a capturing
+  !     stream would end the recording half way);
+  !   * every array must be where it was when the next cycle starts: the in-place kernels keep them; the
+  !     out-of-place fused smoother swaps a level's array with its partner once per pass, and only level 1
+  !     makes an even number of passes per cycle (ceil(ms/2) down and up) - so no level below it may use it;
+  !   * it must pay: 2-D levels from ~180^2 points on (below, a cycle is a handful of launches - sweeps of a
+  !     whole level and the tail are one each - and a replay costs more than it saves: 64^3 calls measured 12-13
+  !     ms without, 14.5 ms with), 3-D solves up to 16 M points (dispatch latency, not bandwidth).
+  function graph_eligible(s) result(ok)
+    type(mg_solver), intent(in) :: s
+    logical :: ok
+    ok = .false.
+    if (s%slab .or. s%ngrids < 2) return
+    if (tail_first(s, 1) > s%ngrids) then
+      if (ndsmk_solve_exact_on_device(s%lev(s%ngrids)%g) == 0) return
+    end if
+    if (s%ndim == 2) then
+      ok = s%lev(1)%npts >= 32768_ik
+    else if (s%ndim == 3) then
+      ok = s%lev(1)%npts <= 16_ik * 1024_ik * 1024_ik .and. s%lev(2)%npts < 2_ik * 1024_ik * 1024_ik
+    end if
+  end function
 
   ! is the recorded graph still the sequence mg_vcycle + metric would enqueue now?
   function graph_valid(s, lane) result(ok)
@@ -906,7 +936,7 @@ contains
   ! are collected.  Small problems (the six 2-D face solves of the vector potential) are dispatch latency
   ! and one host round trip per cycle when run one after the other; side by side the device overlaps them.
   ! Each solve runs exactly the kernels mg_solve would have run for it, in the same order: same bits, same
-  ! cycle counts.  Solvers that would take mg_solve's tracked or mixed path are not accepted.
+  ! cycle counts.  Solvers that would take mg_solve's mixed-precision path are not accepted.
   ! Before the call: whatever the solves read (right-hand sides, initial guesses) was enqueued on the MAIN
   ! stream; after it the main stream has waited for every lane.
   function mg_solve_lanes(ss, vc_tol, nmax, du_last, ncycles, ierr) result(rc)
@@ -919,27 +949,30 @@ contains
     logical :: active(size(ss))
     real(wp) :: met(2), du
     integer :: it, l, nl, st
-    logical :: graphs
+    integer(ik) :: vc0
+    integer :: q
+    logical :: graphs(size(ss))
+    type(dev_level), allocatable :: keep_dl(:)
 
     nl = size(ss)
     rc = NDSMK_EARG
     if (nl < 1 .or. nl > 6 .or. size(du_last) < nl .or. size(ncycles) < nl .or. size(ierr) < nl) return
+    ! (a solver that mg_solve would run in its tracked form - metric inside the last sweep's launch, rotating
+    ! buffers - runs the plain form here: V-cycle, then the metric pass; the same bits, and the tracked form's
+    ! metric scratch is one per process)
     do l = 1, nl
-      if (mg_mixed_applies(ss(l)) .or. mg_track_applies(ss(l)) .or. ss(l)%slab) return
+      if (mg_mixed_applies(ss(l)) .or. ss(l)%slab) return
     end do
     du_last(1:nl) = huge(du); ncycles(1:nl) = 0; ierr(1:nl) = 1
     active = .true.
     ! From the second round on a solve replays its V-cycle + metric as ONE graph launch, recorded in the second
     ! round of the first call (the first round runs plain: every lazily created scratch exists afterwards) and
-    ! kept with the solver while its arrays and parameters stay what they were.  2-D only: those cycles are
-    ! ~190 launches of a few microseconds and nothing in them depends on the host; a 3-D level-1 array swaps
-    ! with its partner from cycle to cycle.  NDSM_HIP_NO_GRAPHS=1: always enqueue kernel by kernel (same bits).
+    ! kept with the solver while its arrays and parameters stay what they were - where graph_eligible says a
+    ! cycle can be recorded and is worth it (the 2-D face solves: ~190 launches of a few microseconds per cycle;
+    ! the 3-D component solves of small grids).  NDSM_HIP_NO_GRAPHS=1: always enqueue kernel by kernel (same bits).
     call get_environment_variable("NDSM_HIP_NO_GRAPHS", status=st)
-    graphs = (st /= 0)
     do l = 1, nl
-      ! (below ~180^2 points a cycle is a handful of launches - sweeps of a whole level and the tail are one each -
-      ! and replaying a graph costs more than it saves: 64^3 calls measured 12-13 ms without, 14.5 ms with)
-      if (ss(l)%ndim /= 2 .or. ss(l)%lev(1)%npts < 32768_ik) graphs = .false.
+      graphs(l) = (st /= 0) .and. graph_eligible(ss(l))
     end do
     do l = 1, nl
       rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800
@@ -951,26 +984,38 @@ contains
       do l = 1, nl
         if (.not. active(l)) cycle
         rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800
-        if (graphs .and. it >= 2) then
+        if (graphs(l) .and. it >= 2) then
           if (.not. graph_valid(ss(l), l - 1)) then
             call drop_graph(ss(l))
             rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800   ! (drop_graph drains the device only)
+            ! Recording RUNS the host side of the cycle without running the device side: whatever the host changes
+            ! on the way - the cycle counter, a level's array swapping places with its partner after an
+            ! out-of-place pass - is put back afterwards, and a cycle that does not leave every array where it
+            ! found it (an odd number of such passes: even ms on a fused level 1) cannot be replayed at all.
+            call graph_stamp(ss(l), l - 1)
+            keep_dl = ss(l)%dl
             rc = ndsmk_capture_begin()
             if (rc == 0) then
+              vc0 = ss(l)%vcycles_done
               rc = mg_vcycle(ss(l))
               if (rc == 0) rc = ndsmk_diff_metrics_begin(ss(l)%dl(1)%u, ss(l)%prev, ss(l)%npts1, 1_c_int)
               rc2 = ndsmk_capture_end(ss(l)%graph)
               if (rc == 0) rc = rc2
-              ss(l)%vcycles_done = ss(l)%vcycles_done - 1     ! (recorded, not run: the replay below counts)
+              ss(l)%vcycles_done = vc0                        ! (recorded, not run: the replay below counts)
+              if (rc == 0) then
+                do q = 1, size(keep_dl)
+                  if (.not. c_associated(keep_dl(q)%u, ss(l)%dl(q)%u)) rc = NDSMK_EARG
+                end do
+              end if
+              ss(l)%dl = keep_dl
             end if
             if (rc /= 0) then       ! recording is an optimisation: without it the round is enqueued as usual
-              ss(l)%graph = c_null_ptr
-              graphs = .false.
-            else
-              call graph_stamp(ss(l), l - 1)
+              call drop_graph(ss(l))
+              rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800
+              graphs(l) = .false.
             end if
           end if
-          if (graphs) then
+          if (graphs(l)) then
             rc = ndsmk_graph_launch(ss(l)%graph); if (rc /= 0) goto 800
             ss(l)%vcycles_done = ss(l)%vcycles_done + 1
             cycle

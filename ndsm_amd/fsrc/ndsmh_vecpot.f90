@@ -66,6 +66,9 @@ module ndsmh_vecpot
   ! (:647-650, :663-666, :679-682; later writes win on shared edges)
   integer, parameter :: face_order(4, 3) = reshape([3, 4, 5, 6, 1, 2, 5, 6, 1, 2, 3, 4], [4, 3])
 
+  ! up to this many points the three 3-D component solves get a hierarchy each and run side by side (vecpot_run)
+  integer(ik), parameter :: SIDE3D_MAX = 16_ik * 1024_ik * 1024_ik
+
   type :: face_data
     integer :: n1 = 0, n2 = 0
     real(wp), allocatable :: bn(:, :), chi(:, :), at1(:, :), at2(:, :)
@@ -77,8 +80,10 @@ module ndsmh_vecpot
     integer(c_int32_t) :: n3(3) = 0
     integer :: ngr = 0
     real(wp), allocatable :: qx(:), qy(:), qz(:)
-    type(mg_solver) :: s3, s2(6)            ! one 2-D hierarchy per face: the six face solves run side by side
-    logical :: live3 = .false., live2(6) = .false.
+    type(mg_solver) :: s3v(3), s2(6)        ! one 2-D hierarchy per face: the six face solves run side by side;
+                                            ! s3v(1): the 3-D hierarchy; s3v(2:3): small grids only, where the three
+                                            ! component solves run side by side as well (live3x)
+    logical :: live3 = .false., live3x = .false., live2(6) = .false.
     type(c_ptr) :: dA = c_null_ptr, dB = c_null_ptr, dmesh = c_null_ptr
     type(c_ptr) :: dbn = c_null_ptr, dchi = c_null_ptr, dphi = c_null_ptr   ! packed faces: B.n, chi; six fluxes
     type(c_ptr) :: hbn = c_null_ptr                                         ! pinned staging of the six faces
@@ -289,8 +294,11 @@ contains
     integer :: p
     integer(c_int) :: rc
     rc = ndsmk_bg_drain()
-    if (ctx%live3) call mg_destroy(ctx%s3)
-    ctx%live3 = .false.
+    if (ctx%live3) call mg_destroy(ctx%s3v(1))
+    if (ctx%live3x) then
+      call mg_destroy(ctx%s3v(2)); call mg_destroy(ctx%s3v(3))
+    end if
+    ctx%live3 = .false.; ctx%live3x = .false.
     do p = 1, 6
       if (ctx%live2(p)) call mg_destroy(ctx%s2(p))
       ctx%live2(p) = .false.
@@ -429,8 +437,8 @@ contains
     real(wp), pointer, contiguous :: hA(:, :, :, :), hB(:, :, :, :), stage(:)
     integer(c_int32_t) :: n3(3)
     integer :: f, c, i, ierr2d, ierr3d, ncyc, st
-    integer :: ncyc6(6), ierr6(6)
-    real(wp) :: du6(6)
+    integer :: ncyc6(6), ierr6(6), ncyc3(3), ierr3(3)
+    real(wp) :: du6(6), du3(3)
     character(len=8) :: envbuf
     integer(ik) :: sweeps, bad, npts, cnt
     integer(c_int) :: tick_up(3), tick, zero_flag, rcb
@@ -465,9 +473,27 @@ contains
     ! ---- device arrays of this call ----------------------------------
     if (.not. ctx%live3) then
       bc3 = 'D'; bc3(1) = 'N'; bc3(4) = 'N'
-      rc = mg_create(ctx%s3, 3, n3, ctx%qx, ctx%qy, ctx%qz, bc3, ctx%ngr); ctx%live3 = .true.
+      rc = mg_create(ctx%s3v(1), 3, n3, ctx%qx, ctx%qy, ctx%qz, bc3, ctx%ngr); ctx%live3 = .true.
       if (rc /= 0) return
-      rc = mg_zero_rhs(ctx%s3); if (rc /= 0) return                ! :640-641 rhs = 0
+      rc = mg_zero_rhs(ctx%s3v(1)); if (rc /= 0) return            ! :640-641 rhs = 0
+      ! The three component solves are independent (:643-689).  Up to a few million points a V-cycle is ~150 launches
+      ! of a few microseconds each - dispatch latency, not bandwidth - and one host round trip: with a hierarchy per
+      ! component they run side by side on three streams (mg_solve_lanes, as the six face solves do), each one the
+      ! kernels it would run alone in the same order.  NDSM_HIP_NO_SIDE3D=1: one after the other (same bits).
+      call get_environment_variable("NDSM_HIP_NO_SIDE3D", status=st)
+      if (npts <= SIDE3D_MAX .and. st /= 0) then
+        do c = 2, 3
+          rc = mg_create(ctx%s3v(c), 3, n3, ctx%qx, ctx%qy, ctx%qz, bc3, ctx%ngr)
+          if (rc == 0) rc = mg_zero_rhs(ctx%s3v(c))
+          if (rc /= 0) then                                          ! (no memory for them: one after the other)
+            call mg_destroy(ctx%s3v(c))
+            if (c == 3) call mg_destroy(ctx%s3v(2))
+            rc = 0
+            exit
+          end if
+          if (c == 3) ctx%live3x = .true.
+        end do
+      end if
     end if
     resident = .true.
     if (on_device) then
@@ -570,77 +596,27 @@ contains
 
     ! ---- 4. the three 3-D Laplace problems ----------------------------
     call say(me, "Solve BVP 3D...")
-    associate (s3 => ctx%s3)
-      s3%ex_tol = ropt(ROPT_CTOL); s3%use_max = use_max; s3%nmax_exact = int(iopt(IOPT_NMAXEX))
-      s3%precision = int(iopt(IOPT_PREC))
+    if (ctx%live3x .and. iopt(IOPT_PREC) == 0) then
       do c = 1, 3
-        ! initial guess of component c -> the solver's level-1 array
-        u3 = mg_level_ptr(s3, 1, MG_BUF_U, cnt)
-        if (on_device) then
-          rc = ndsmk_d2d(u3, dptr_offset(pA, int(c - 1, c_size_t) * nb), nb); if (rc /= 0) goto 900
-        else
-          rc = ndsmk_bg_wait(tick_up(c), zero_flag); if (rc /= 0) goto 900
-          if (zero_flag /= 0) then
-            rc = ndsmk_fill0(u3, nb)
-          else
-            rc = ndsmk_d2d(u3, dptr_offset(ctx%dA, int(c - 1, c_size_t) * nb), nb)
-          end if
-          if (rc /= 0) goto 900
-        end if
-        ! its Dirichlet data: A_t on the four tangential faces, in the reference's order (later writes
-        ! win on shared edges, :647-650, :663-666, :679-682)
-        do i = 1, 4
-          f = face_order(i, c)
-          if (host_faces) then
-            rc = face_upload(u3, n3, f, merge(1, 2, face_t1(f) == c), fc(f)); if (rc /= 0) goto 900
-          else
-            fac = 1.0_wp / (2.0_wp * dq(face_axis(f)))            ! Q4: the normal spacing
-            rc = ndsmk_face_write(u3, n3, ctx%dchi, int(f - 1, c_int), int(c - 1, c_int), fac); if (rc /= 0) goto 900
-          end if
-        end do
-        bc3 = 'D'
-        bc3(c) = 'N'; bc3(3 + c) = 'N'                        ! :655,:671,:687
-        rc = mg_set_bcs(s3, bc3); if (rc /= 0) goto 900
-        s3%ms = merge(5, int(iopt(IOPT_MS)), c == 3)          ! Q2
-        rc = mg_reset_info(s3); if (rc /= 0) goto 900
-        rc = mg_solve(s3, ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du_last, ncyc, ierr3d)
-        if (rc /= 0) goto 900
-        rc = mg_export_u(s3, dptr_offset(dAout, int(c - 1, c_size_t) * nb)); if (rc /= 0) goto 900
-        if (ierr3d /= 0) print *, "Warning: IOPT_NCYCLES exceeded. V-cycle iteration may not have converged"
-        if (mg_read_info(s3, sweeps, bad) == 0) then
-          if (bad > 0) print *, "Warning: IOPT_NMAXEX exceeded. Coarse-mesh solution may not have converged"
-        end if
-        if (ierr3d /= 0) iopt(IOPT_FAIL3D) = ior(iopt(IOPT_FAIL3D), ishft(1_ik, c - 1))
-        if (ncyc > 1 .or. c == 1) then
-          iopt(IOPT_NCYC_OUT) = ncyc
-          ropt(ROPT_DULAST) = du_last
-        end if
-        ! default order (:467-477): the flux-balance fields come before the curl, so this component is final
-        ! once its own field is added - and goes home behind the next component's solve
-        if (.not. late_balance) then
-          rc = ndsmk_balance_component(dptr_offset(dAout, int(c - 1, c_size_t) * nb), n3, int(c - 1, c_int), ctx%dmesh, &
-                                       dptr_offset(ctx%dmesh, off_y), dptr_offset(ctx%dmesh, off_z), phi, span)
-          if (rc /= 0) goto 900
-          if (.not. on_device) then
-            rc = ndsmk_bg_download(c_loc(hA(1, 1, 1, c)), dptr_offset(dAout, int(c - 1, c_size_t) * nb), nb, tick)
-            if (rc /= 0) goto 900
-          end if
-          ! B_z = d(A_y)/dx - d(A_x)/dy needs the two components that are final now: it is formed here and goes
-          ! home behind the A_z solve as well (when B's device array exists already: not on the lean path)
-          call get_environment_variable("NDSM_HIP_NO_EARLY_BZ", status=st)      ! A/B testing: one curl at the end
-          if (c == 2 .and. c_associated(dBout) .and. all(n3 >= 3) .and. st /= 0) then
-            rc = ndsmk_curl_component(dAout, dBout, n3, dq, 2_c_int); if (rc /= 0) goto 900
-            if (.not. on_device) then
-              rc = ndsmk_bg_download(c_loc(hB(1, 1, 1, 3)), dptr_offset(dBout, 2_c_size_t * nb), nb, tick)
-              if (rc /= 0) goto 900
-            end if
-            bz_done = .true.
-          end if
-        end if
+        rc = prep3(ctx%s3v(c), c); if (rc /= 0) goto 900
       end do
-    end associate
+      rc = mg_solve_lanes(ctx%s3v, ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du3, ncyc3, ierr3); if (rc /= 0) goto 900
+      do c = 1, 3
+        rc = finish3(ctx%s3v(c), c, du3(c), ncyc3(c), ierr3(c)); if (rc /= 0) goto 900
+      end do
+    else
+      do c = 1, 3
+        rc = prep3(ctx%s3v(1), c); if (rc /= 0) goto 900
+        rc = mg_solve(ctx%s3v(1), ropt(ROPT_VTOL), int(iopt(IOPT_NCYCLES)), du_last, ncyc, ierr3d)
+        if (rc /= 0) goto 900
+        rc = finish3(ctx%s3v(1), c, du_last, ncyc, ierr3d); if (rc /= 0) goto 900
+      end do
+    end if
     if (.not. on_device .and. .not. c_associated(ctx%dB)) then      ! HBM too small for both (see above)
-      call mg_destroy(ctx%s3); ctx%live3 = .false.
+      call mg_destroy(ctx%s3v(1)); ctx%live3 = .false.
+      if (ctx%live3x) then
+        call mg_destroy(ctx%s3v(2)); call mg_destroy(ctx%s3v(3)); ctx%live3x = .false.
+      end if
       rc = ndsmk_alloc(ctx%dB, 3_c_size_t * nb); if (rc /= 0) goto 900
       dBout = ctx%dB
     end if
@@ -674,6 +650,89 @@ contains
     if (.not. resident) then                                ! keep the peak at A + one hierarchy next time too
       rcb = ndsmk_free(ctx%dB); ctx%dB = c_null_ptr
     end if
+
+  contains
+
+    ! component c of the 3-D phase on solver s3: initial guess, Dirichlet data, boundary letters, options
+    function prep3(s3, c) result(rc)
+      type(mg_solver), intent(inout) :: s3
+      integer, intent(in) :: c
+      integer(c_int) :: rc
+      integer :: i, f
+      s3%ex_tol = ropt(ROPT_CTOL); s3%use_max = use_max; s3%nmax_exact = int(iopt(IOPT_NMAXEX))
+      s3%precision = int(iopt(IOPT_PREC))
+      ! initial guess of component c -> the solver's level-1 array
+      u3 = mg_level_ptr(s3, 1, MG_BUF_U, cnt)
+      if (on_device) then
+        rc = ndsmk_d2d(u3, dptr_offset(pA, int(c - 1, c_size_t) * nb), nb); if (rc /= 0) return
+      else
+        rc = ndsmk_bg_wait(tick_up(c), zero_flag); if (rc /= 0) return
+        if (zero_flag /= 0) then
+          rc = ndsmk_fill0(u3, nb)
+        else
+          rc = ndsmk_d2d(u3, dptr_offset(ctx%dA, int(c - 1, c_size_t) * nb), nb)
+        end if
+        if (rc /= 0) return
+      end if
+      ! its Dirichlet data: A_t on the four tangential faces, in the reference's order (later writes
+      ! win on shared edges, :647-650, :663-666, :679-682)
+      do i = 1, 4
+        f = face_order(i, c)
+        if (host_faces) then
+          rc = face_upload(u3, n3, f, merge(1, 2, face_t1(f) == c), fc(f)); if (rc /= 0) return
+        else
+          fac = 1.0_wp / (2.0_wp * dq(face_axis(f)))            ! Q4: the normal spacing
+          rc = ndsmk_face_write(u3, n3, ctx%dchi, int(f - 1, c_int), int(c - 1, c_int), fac); if (rc /= 0) return
+        end if
+      end do
+      bc3 = 'D'
+      bc3(c) = 'N'; bc3(3 + c) = 'N'                        ! :655,:671,:687
+      rc = mg_set_bcs(s3, bc3); if (rc /= 0) return
+      s3%ms = merge(5, int(iopt(IOPT_MS)), c == 3)          ! Q2
+      rc = mg_reset_info(s3)
+    end function
+
+    ! ... and what follows its solve: the result into A, the reference's warnings and outputs, its flux-balance
+    ! field, its way home
+    function finish3(s3, c, du_c, ncyc_c, ierr_c) result(rc)
+      type(mg_solver), intent(inout) :: s3
+      integer, intent(in) :: c, ncyc_c, ierr_c
+      real(wp), intent(in) :: du_c
+      integer(c_int) :: rc
+      integer :: st3
+      rc = mg_export_u(s3, dptr_offset(dAout, int(c - 1, c_size_t) * nb)); if (rc /= 0) return
+      if (ierr_c /= 0) print *, "Warning: IOPT_NCYCLES exceeded. V-cycle iteration may not have converged"
+      if (mg_read_info(s3, sweeps, bad) == 0) then
+        if (bad > 0) print *, "Warning: IOPT_NMAXEX exceeded. Coarse-mesh solution may not have converged"
+      end if
+      if (ierr_c /= 0) iopt(IOPT_FAIL3D) = ior(iopt(IOPT_FAIL3D), ishft(1_ik, c - 1))
+      if (ncyc_c > 1 .or. c == 1) then
+        iopt(IOPT_NCYC_OUT) = ncyc_c
+        ropt(ROPT_DULAST) = du_c
+      end if
+      ! default order (:467-477): the flux-balance fields come before the curl, so this component is final
+      ! once its own field is added - and goes home behind the next component's solve
+      if (.not. late_balance) then
+        rc = ndsmk_balance_component(dptr_offset(dAout, int(c - 1, c_size_t) * nb), n3, int(c - 1, c_int), ctx%dmesh, &
+                                     dptr_offset(ctx%dmesh, off_y), dptr_offset(ctx%dmesh, off_z), phi, span)
+        if (rc /= 0) return
+        if (.not. on_device) then
+          rc = ndsmk_bg_download(c_loc(hA(1, 1, 1, c)), dptr_offset(dAout, int(c - 1, c_size_t) * nb), nb, tick)
+          if (rc /= 0) return
+        end if
+        ! B_z = d(A_y)/dx - d(A_x)/dy needs the two components that are final now: it is formed here and goes
+        ! home behind the A_z solve as well (when B's device array exists already: not on the lean path)
+        call get_environment_variable("NDSM_HIP_NO_EARLY_BZ", status=st3)      ! A/B testing: one curl at the end
+        if (c == 2 .and. c_associated(dBout) .and. all(n3 >= 3) .and. st3 /= 0) then
+          rc = ndsmk_curl_component(dAout, dBout, n3, dq, 2_c_int); if (rc /= 0) return
+          if (.not. on_device) then
+            rc = ndsmk_bg_download(c_loc(hB(1, 1, 1, 3)), dptr_offset(dBout, 2_c_size_t * nb), nb, tick)
+            if (rc /= 0) return
+          end if
+          bz_done = .true.
+        end if
+      end if
+    end function
   end function
 
   ! B.n of face f (1..6) from the host field (extract_bn, :699-743)

@@ -139,3 +139,37 @@ def test_cached_context_is_evicted_when_memory_runs_out(hip):
             L.ndsm_hip_device_free(p)
     ierr2, A2, B2 = ndsm_amd.vector_potential(x, y, z, b1)            # rebuilt on demand, same bits
     assert np.array_equal(A, A2) and np.array_equal(B, B2)
+
+
+@pytest.mark.parametrize("shape", ([64, 64, 64], [200, 200, 184], [45, 38, 51]), ids=lambda ns: "x".join(str(n) for n in ns))
+def test_component_solves_side_by_side_bitwise(hip, shape):
+    """small grids: the three 3-D component solves on three streams, a hierarchy each, their cycles replayed as
+    recorded graphs where a cycle leaves every array in place (the default up to 16 M points) against one after
+    the other on one hierarchy (NDSM_HIP_NO_SIDE3D=1, a fresh context) - the same A and B bit for bit, over a
+    sequence of calls with changing options.  Even ms on a grid whose level 1 runs the out-of-place smoother
+    swaps that level's arrays an odd number of times per cycle: such a cycle must NOT be replayed."""
+    import ndsm_amd
+    L = hip.load_library()
+    x, y, z, _A1, b1 = analytic_case(shape)
+    b = b1 + 0.05 * np.random.default_rng(5).standard_normal(b1.shape)     # all three components iterate
+    seq = [dict(), dict(ms=3, mean=True), dict(), dict(ms=4), dict(), dict(ms=2), dict(ms=1), dict()]
+
+    def run():
+        L.ndsm_hip_shutdown()                      # drop the cached context: the switch is read when it is built
+        assert L.ndsm_hip_init(0) == 0
+        return [ndsm_amd.vector_potential(x, y, z, b, **kw) for kw in seq]
+
+    keep = os.environ.get("NDSM_HIP_NO_SIDE3D")
+    try:
+        os.environ["NDSM_HIP_NO_SIDE3D"] = "1"
+        want = run()
+        os.environ.pop("NDSM_HIP_NO_SIDE3D")
+        got = run()
+    finally:
+        if keep is None:
+            os.environ.pop("NDSM_HIP_NO_SIDE3D", None)
+        else:
+            os.environ["NDSM_HIP_NO_SIDE3D"] = keep
+    for i, (w, g) in enumerate(zip(want, got)):
+        assert w[0] == g[0], (i, seq[i])
+        assert np.array_equal(w[1], g[1]) and np.array_equal(w[2], g[2]), (i, seq[i])
