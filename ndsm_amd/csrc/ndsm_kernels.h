@@ -69,7 +69,8 @@ typedef struct {
   int32_t c_k0;           /* global index of plane 0 of the coarse array */
   int32_t c_beg, c_cnt;   /* local coarse planes [c_beg, c_beg+c_cnt) are written by restrict */
   int32_t stream_ok;      /* host-checked, restrict_stream.hip: bit 1 its tile covers this pair's taps,
-                             bit 0 and the level is large enough for it to be the default */
+                             bit 0 and the level is large enough for it to be the default; bit 2 + bits 8-31:
+                             what the scheduled form needs to know about the z windows (launch_rs_t) */
 } ndsmk_xfer;
 
 /* ---- runtime ------------------------------------------------------- */

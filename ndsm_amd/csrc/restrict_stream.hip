@@ -514,7 +514,7 @@ __global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__re
   // SCHED: that walk costs three to five dependent LDS round trips (window starts, lengths, weights, each read
   // made wave-uniform with a readfirstlane) before the first multiplication of every plane-step.  The answers do
   // not depend on the data: a schedule per fine plane of the chunk - first coarse plane that takes it, how many do
-  // (up to 4 recorded; any further ones are walked), their z weights, which of them it completes - is built once
+  // (at most 4: launch_rs_t refuses this form for a level pair with more), their z weights, which of them it completes - is built once
   // from the z tables, and the record of plane k+1 is read while plane k's step drains into its barrier.
   constexpr int KPL = SCHED ? 2 * KCMAX + 16 : 1;
   __shared__ int s_sk[KPL], s_sc[KPL];
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__re
   int rk = 0, rc = 0;
   double rw0 = 0.0, rw1 = 0.0, rw2 = 0.0, rw3 = 0.0;
   auto read_rec = [&](int k) {
-    const int t = min(k - kA, nrec - 1);
+    const int t = max(min(k - kA, nrec - 1), 0);
     rk = s_sk[t];
     rc = k - kA < nrec ? s_sc[t] : 0;
     rw0 = s_sw[4 * t];
@@ -531,8 +531,8 @@ __global__ __launch_bounds__(CI *CJ, WPS) void restrict_stream2_k(const TF *__re
     rw2 = s_sw[4 * t + 2];
     rw3 = s_sw[4 * t + 3];
   };
-  // (the host only selects this form where a chunk has at most KPL fine planes and no fine plane lies in more
-  // than four coarse windows: ndsmh_mg.f90:stream_restrict_applies)
+  // (launch_rs_t only selects this form where a chunk has at most KPL fine planes and no fine plane lies in more
+  // than four coarse windows - numbers the host measures per level pair, ndsmh_mg.f90:stream_restrict_applies)
   auto consume_s = [&](const double *R) {
     const int cc = __builtin_amdgcn_readfirstlane(rc);
     const int cnt = cc & 255, done = cc >> 8;
@@ -735,7 +735,14 @@ static int launch_rs_v(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double
 template <typename TF>
 static int launch_rs_t(const ndsmk_xfer *x, const TF *r_f, double *rhs_c, double *u_c) {
   int v = rs_variant();
-  if ((v == 8 || v == 9) && !(x->stream_ok & 4)) v = 5;   // the scheduled forms need the host's word on the z windows
+  // The scheduled forms hold a chunk's z windows in a fixed-size table: at most four coarse windows per fine plane
+  // (consume_s has four weight slots) and at most 2 * kKCMax + 16 fine planes per chunk (KPL records).  The host
+  // measures both for a level pair (ndsmh_mg.f90: stream_restrict_applies); they are checked HERE, against the
+  // kernel's limits - a descriptor that does not carry the numbers takes the table walk instead.
+  {
+    const int wmax = (x->stream_ok >> 8) & 255, smax = (x->stream_ok >> 16) & 32767;
+    if ((v == 8 || v == 9) && (!(x->stream_ok & 4) || wmax < 1 || wmax > 4 || smax < 1 || smax > 2 * kKCMax + 16)) v = 5;
+  }
   switch (v) {
     case 0: return launch_rs_v<TF, 8, 4, true>(x, r_f, rhs_c, u_c);
     case 2: return launch_rs_v<TF, 4, 4, false, 2>(x, r_f, rhs_c, u_c);

@@ -93,7 +93,8 @@ bool host_all_zero(const void *p, size_t bytes) {
 
 // First touch of a host array the call is going to overwrite completely (numpy.zeros / numpy.empty hand over
 // untouched pages): a device-to-host copy into untouched pages runs at ~13 GB/s on this box (the page faults are
-// taken one by one inside the copy), into touched ones at ~50.  Four threads write one word per 4 KiB page.
+// taken one by one inside the copy), into touched ones at ~50.  Four threads rewrite one word per 4 KiB page with
+// its own value: the caller's data is intact if the call fails later.
 void host_first_touch(void *p, size_t bytes) {
   unsigned nt = std::thread::hardware_concurrency();
   nt = nt > 4 ? 4 : (nt < 1 ? 1 : nt);
@@ -102,7 +103,10 @@ void host_first_touch(void *p, size_t bytes) {
   auto touch = [&](unsigned t) {
     const size_t a = (bytes / nt) * t, b = t + 1 == nt ? bytes : (bytes / nt) * (t + 1);
     size_t o = ((reinterpret_cast<size_t>(base) + a + page - 1) & ~(page - 1)) - reinterpret_cast<size_t>(base);
-    for (; o + 8 <= b; o += page) *reinterpret_cast<volatile unsigned long long *>(base + o) = 0ull;
+    for (; o + 8 <= b; o += page) {   // write back what is there: the page is faulted in, its contents stay
+      volatile unsigned long long *w = reinterpret_cast<volatile unsigned long long *>(base + o);
+      *w = *w;
+    }
   };
   std::vector<std::thread> th;
   for (unsigned t = 1; t < nt; ++t) th.emplace_back(touch, t);
@@ -502,8 +506,8 @@ int ndsmk_bg_download(void *h_dst, const void *d_src, size_t bytes, int *ticket)
   return bg_submit(j, ticket);
 }
 
-// queue: touch every page of a host array that this call will overwrite completely (its present contents
-// are destroyed: one word per page is zeroed) - ahead of the downloads into it
+// queue: touch every page of a host array that this call will overwrite completely (a write fault per page;
+// the contents are not changed) - ahead of the downloads into it
 int ndsmk_bg_first_touch(void *h_dst, size_t bytes, int *ticket) {
   NDSM_REQUIRE_READY();
   NDSM_CHECK_ARG(h_dst && ticket);

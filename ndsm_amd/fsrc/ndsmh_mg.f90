@@ -291,28 +291,28 @@ contains
     end do
     ok = 2
     if (s%lev(l)%npts >= 6_ik * 1024_ik * 1024_ik) ok = 3
-    ! bit 2: the kernel's per-chunk schedule holds this pair's z windows - no fine plane lies in more than four
-    ! coarse windows, and 64 consecutive coarse planes (the longest chunk) span at most 144 fine planes
+    ! What the kernel's per-chunk SCHEDULE of the z windows has to hold, MEASURED here and checked by the launcher
+    ! against the kernel's own limits (restrict_stream.hip: launch_rs_t): bits 8-15 the largest number of coarse
+    ! windows a fine plane lies in, bits 16-31 the most fine planes 64 consecutive coarse planes (the longest
+    ! chunk) span.  Bit 2: measured (a descriptor without these numbers never takes the scheduled form).
     block
-      integer :: cntf(0:t(3)%nf), kk
-      logical :: sched
+      integer :: cntf(0:t(3)%nf), kk, wmax, smax
       cntf = 0
       do k = 1, t(3)%nc
         cntf(t(3)%rlo(k)) = cntf(t(3)%rlo(k)) + 1
         kk = t(3)%rlo(k) + t(3)%rcnt(k)
         if (kk <= t(3)%nf) cntf(kk) = cntf(kk) - 1
       end do
-      sched = .true.
-      kk = 0
+      kk = 0; wmax = 0; smax = 0
       do k = 0, t(3)%nf - 1
         kk = kk + cntf(k)
-        if (kk > 4) sched = .false.
+        wmax = max(wmax, kk)
       end do
       do k = 1, t(3)%nc
         a1 = min(k + 63, int(t(3)%nc))
-        if (t(3)%rlo(a1) + t(3)%rcnt(a1) - t(3)%rlo(k) > 144) sched = .false.
+        smax = max(smax, t(3)%rlo(a1) + t(3)%rcnt(a1) - t(3)%rlo(k))
       end do
-      if (sched) ok = ok + 4
+      ok = ok + 4 + 256 * min(wmax, 255) + 65536 * min(smax, 32767)
     end block
   end function
 

@@ -293,7 +293,9 @@ contains
     type(vecpot_ctx), intent(inout) :: ctx
     integer :: p
     integer(c_int) :: rc
-    rc = ndsmk_bg_drain()
+    ! (no transfer of this context is in flight here: vecpot_run drains its own before it returns, whatever its
+    ! outcome - and draining here would void the tickets of ANOTHER context's running call when the low-memory
+    ! hook evicts the cached one from inside it)
     if (ctx%live3) call mg_destroy(ctx%s3v(1))
     if (ctx%live3x) then
       call mg_destroy(ctx%s3v(2)); call mg_destroy(ctx%s3v(3))
@@ -375,7 +377,8 @@ contains
   ! a device allocation somewhere in the library has failed: the cached context (13 GiB at 512^3) is only a
   ! convenience - give it back, unless ndsm_vector_solve is using it right now
   subroutine vecpot_cache_evict() bind(c)
-    if (.not. cache_busy) call vecpot_ctx_destroy(cache)
+    if (.not. cache%live .or. cache_busy) return
+    call vecpot_ctx_destroy(cache)
   end subroutine
 
   function vecpot_solve(n3, iopt, ropt, qx, qy, qz, A, B) result(rc)

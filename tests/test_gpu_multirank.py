@@ -36,10 +36,11 @@ def _fake():
     return FAKE
 
 
-def _run_world(tmp_path, world, cases, timeout=300, worker="multirank_worker.py"):
+def _run_world(tmp_path, world, cases, timeout=300, worker="multirank_worker.py", extra_env=None):
     out = str(tmp_path)
     json.dump(cases, open(os.path.join(out, "cases.json"), "w"))
     env = dict(os.environ, NDSM_HIP_LIB=_fake(), FAKE_RCCL_TIMEOUT="60")
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker), str(r), str(world), out],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs, codes = [], []
@@ -163,6 +164,35 @@ def test_distributed_vector_potential_bitwise(hip, tmp_path, world):
         gB = np.concatenate([np.load(os.path.join(out, f"v{ci}_B_r{r}.npy")) for r in range(world)], axis=1)
         assert np.array_equal(gA, A), (ci, np.abs(gA - A).max())
         assert np.array_equal(gB, B), (ci, np.abs(gB - B).max())
+
+
+def test_baseline_config4_workload_four_ranks(hip, tmp_path):
+    """BASELINE config[4] AS A WORKLOAD - the distributed vector-potential pipeline (ndsm_hip_world_vector_solve: faces
+    on rank 0, three 3-D solves on z-slab worlds, flux balance + curl on the slabs) in its mixed fp32-smoother /
+    fp64-residual mode - at 640 x 640 x 320 (131 M points, 1 GiB per fp64 array) on four processes over the test
+    double, against ndsm_vector_solve in the same mode on the whole field: every rank's planes of A and B bit for
+    bit, all three components iterating.  (Four ranks: the pool's process guard allows six GPU processes on a box.
+    The grid of config[4] itself, 2048 x 2048 x 1024, runs in this mode as ONE component on one GPU against eight
+    loop-back slabs in test_gpu_parity.py::test_baseline_config4_full_grid_mixed_component; what stays 8-GPU-only is
+    the whole pipeline at that size - 3 x 32 GiB of A and of B next to a hierarchy - and real RCCL / xGMI.)"""
+    import ndsm_amd
+    from golden_inputs import analytic_case
+    cases = [{"ns": [640, 640, 320], "noise": 11, "kw": {"mixed_precision": 1}}]
+    out = _run_world(tmp_path, 4, cases, timeout=1200, worker="multirank_vecpot_worker.py",
+                     extra_env={"FAKE_RCCL_TIMEOUT": "300", "FAKE_RCCL_SLOT_MB": "32"})
+    c = cases[0]
+    x, y, z, _A1, b = analytic_case(c["ns"])
+    b = b + 0.3 * np.random.default_rng(c["noise"]).uniform(-1, 1, b.shape)
+    ierr, A, B = ndsm_amd.vector_potential(x, y, z, b, **c["kw"])
+    del b
+    infos = [json.load(open(os.path.join(out, f"v0_r{r}.json"))) for r in range(4)]
+    assert all(i["ierr"] == ierr for i in infos), (ierr, infos)
+    for name, want in (("A", A), ("B", B)):
+        for r in range(4):
+            got = np.load(os.path.join(out, f"v0_{name}_r{r}.npy"), mmap_mode="r")
+            z0, z1 = infos[r]["z0"], infos[r]["z1"]
+            assert np.array_equal(got, want[:, z0:z1]), (name, r)
+            os.remove(os.path.join(out, f"v0_{name}_r{r}.npy"))
 
 
 def test_bench_two_ranks_rehearsal(hip):
