@@ -125,20 +125,7 @@ __device__ __forceinline__ void stbuf(__amdgpu_buffer_rsrc_t r, unsigned off, co
     __builtin_amdgcn_raw_buffer_store_b64(a, r, off, 0, AUX);
   }
 }
-// ... and element by element: the rows of an odd-nx level are only sizeof(T)-aligned (a straddling 16-byte access
-// costs 1.35 x more), and the pair that holds the last column takes its second element from elsewhere (header)
-template <typename T>
-__device__ __forceinline__ T ldbuf1(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  T v;
-  if constexpr (sizeof(T) == 8) {
-    const v2u_t a = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
-    __builtin_memcpy(&v, &a, 8);
-  } else {
-    const unsigned a = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
-    __builtin_memcpy(&v, &a, 4);
-  }
-  return v;
-}
+// one element (the last column of an odd-nx level, stored by itself)
 template <typename T, int AUX>
 __device__ __forceinline__ void stbuf1(__amdgpu_buffer_rsrc_t r, unsigned off, const T v) {
   if constexpr (sizeof(T) == 8) {
@@ -285,31 +272,29 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   auto rsrc_of = [&](const T *base, int k_, bool ok) {
     return plane_rsrc(base + sz * (size_t)(ok ? k_ : 0), ok ? plane_bytes : 0u);
   };
-  // a pair through descriptor r: o0 = byte offset of element 0; odd nx: o1 = that of element 1 (the ghost's source
-  // for loads, kDeadLane for its stores)
-  auto ldp = [&](__amdgpu_buffer_rsrc_t r, unsigned o0, unsigned o1) {
+  // A pair through descriptor r, ONE 16-byte (8-byte) access per lane.  Odd nx: rows are only sizeof(T)-aligned,
+  // so half of these accesses straddle a 16-byte boundary - still cheaper than two element-sized ones - and the
+  // pair that holds the last column nx-1 (element 0) keeps a GHOST of column nx-2 as element 1 (header): it is
+  // LOADED one element to the left and swapped (gh: the lane is that pair), and STORED as element 0 only (og).
+  auto ldp = [&](__amdgpu_buffer_rsrc_t r, unsigned off, bool gh) {
+    d2 v = ldbuf<T>(r, off);
     if constexpr (ODD) {
-      d2 v;
-      v.x = ldbuf1<T>(r, o0);
-      v.y = ldbuf1<T>(r, o1);
-      return v;
-    } else {
-      return ldbuf<T>(r, o0);
+      d2 w;
+      w.x = gh ? v.y : v.x;
+      w.y = gh ? v.x : v.y;
+      return w;
     }
+    return v;
   };
-  auto stp = [&](__amdgpu_buffer_rsrc_t r, unsigned o0, unsigned o1, const d2 &v) {
-    if constexpr (ODD) {
-      stbuf1<T, STAUX>(r, o0, v.x);
-      stbuf1<T, STAUX>(r, o1, v.y);
-    } else {
-      stbuf<T, STAUX>(r, o0, v);
-    }
+  auto stp = [&](__amdgpu_buffer_rsrc_t r, unsigned off, unsigned og, const d2 &v) {
+    stbuf<T, STAUX>(r, off, v);
+    if constexpr (ODD) stbuf1<T, STAUX>(r, og, v.x);
   };
 
 #define NDSM_LOAD_PLANE(base, k, dst)                                                                  \
   do {                                                                                                  \
     const auto r_ = plane_rsrc((base) + sz * (size_t)(k), plane_bytes);                                 \
-    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) dst[s_] = ldp(r_, scs[s_].ldo, scs[s_].ldo1);     \
+    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) dst[s_] = ldp(r_, scs[s_].ldo, ODD && (scs[s_].fl & 16));     \
   } while (0)
 
   // Register window per slot (everything else is re-read from LDS):
@@ -352,9 +337,11 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   // and one masked write.
   struct SC {
     int l0, l1;    // where the pair's elements 0 / 1 live in an LDS plane: pair offset + HSTR * (the element's class)
-    unsigned ldo;  // byte offset of the pair inside a global plane for loads (kDeadLane outside the domain) ...
-    unsigned sto;  // ... and for stores / loads of owned points only (kDeadLane for halo pairs)
-    unsigned ldo1, sto1;  // odd nx: the same for element 1 by itself (the ghost: column nx-2 / kDeadLane)
+    unsigned ldo;  // byte offset of the pair inside a global plane for loads (kDeadLane outside the domain; the ghost
+                   // pair of an odd-nx level: one element to the left, ldp) ...
+    unsigned ldq;  // ... the same for loads of owned pairs only (kDeadLane for halo pairs) ...
+    unsigned sto;  // ... and for stores (owned pairs; the ghost pair: kDeadLane, its element 0 goes through stg)
+    unsigned stg;
     int fl;        // bit 0 in-domain, 1 owned, 2/3 element 0/1 inside the x-y update bounds, 4 (ODD) the pair
                    // of column nx-1 whose element 1 is the ghost, 6 the pair's parity: class of its element 0
   };
@@ -397,10 +384,10 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     c.fl = (q_.in ? 1 : 0) | (own ? 2 : 0) | (in0 ? 4 : 0) | (in1 ? 8 : 0) | (ghost ? 16 : 0) | (par ? 64 : 0);
     c.l0 = lo + HSTR * par;
     c.l1 = lo + HSTR - HSTR * par;
-    c.ldo = q_.in ? gob : kDeadLane;
-    c.sto = own ? gob : kDeadLane;
-    c.ldo1 = !q_.in ? kDeadLane : (ghost ? gob - SZ : gob + SZ);
-    c.sto1 = (own && !ghost) ? gob + SZ : kDeadLane;
+    c.ldo = q_.in ? (ghost ? gob - SZ : gob) : kDeadLane;
+    c.ldq = own ? c.ldo : kDeadLane;
+    c.sto = (own && !ghost) ? gob : kDeadLane;
+    c.stg = (own && ghost) ? gob : kDeadLane;
     scs[s] = c;
 #pragma unroll
     for (int cl = 0; cl < 2; ++cl) {
@@ -665,17 +652,17 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     if (MET) {
       const auto rp = rsrc_of(prev, pf, pf_st);
 #pragma unroll
-      for (int s = 0; s < (MET ? NS : 1); ++s) pvh[s] = ldp(rp, scs[s].sto, scs[s].sto1);
+      for (int s = 0; s < (MET ? NS : 1); ++s) pvh[s] = ldp(rp, scs[s].ldq, ODD && (scs[s].fl & 16));
     }
     if (!RHS0) {
       const auto rr_ = rsrc_of(rhs, k + 1, k + 1 <= ke);
 #pragma unroll
-      for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rn[s] = ldp(rr_, scs[s].ldo, scs[s].ldo1);
+      for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rn[s] = ldp(rr_, scs[s].ldo, ODD && (scs[s].fl & 16));
     }
     {
       const auto ru = rsrc_of(u, k + 2, k + 2 <= ke);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) nn[s] = ldp(ru, scs[s].ldo, scs[s].ldo1);
+      for (int s = 0; s < NS; ++s) nn[s] = ldp(ru, scs[s].ldo, ODD && (scs[s].fl & 16));
     }
 
     // ---- the stages ----
@@ -781,11 +768,11 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     if (!DEFER) {   // (planes outside the store window: a descriptor of zero records, nothing is written)
       const auto rs_ = rsrc_of(uout, pf, pf_st);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) stp(rs_, scs[s].sto, scs[s].sto1, finh[s]);
+      for (int s = 0; s < NS; ++s) stp(rs_, scs[s].sto, scs[s].stg, finh[s]);
       if (RES) {
         const auto rr_ = rsrc_of(rout, pr, pr_st);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) stp(rr_, scs[s].sto, scs[s].sto1, resh[RES ? s : 0]);
+        for (int s = 0; s < NS; ++s) stp(rr_, scs[s].sto, scs[s].stg, resh[RES ? s : 0]);
       }
     }
 
@@ -831,7 +818,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       {
         const auto rs_ = rsrc_of(uout, pf, pf_st);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) stp(rs_, scs[s].sto, scs[s].sto1, finh[s]);
+        for (int s = 0; s < NS; ++s) stp(rs_, scs[s].sto, scs[s].stg, finh[s]);
       }
     }
     __syncthreads();
