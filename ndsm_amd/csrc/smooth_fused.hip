@@ -339,8 +339,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     int l0, l1;    // where the pair's elements 0 / 1 live in an LDS plane: pair offset + HSTR * (the element's class)
     unsigned ldo;  // byte offset of the pair inside a global plane for loads (kDeadLane outside the domain; the ghost
                    // pair of an odd-nx level: one element to the left, ldp) ...
-    unsigned ldq;  // ... the same for loads of owned pairs only (kDeadLane for halo pairs) ...
-    unsigned sto;  // ... and for stores (owned pairs; the ghost pair: kDeadLane, its element 0 goes through stg)
+    unsigned sto;  // ... and for stores (owned pairs only; the ghost pair: kDeadLane, its element 0 goes through stg)
     unsigned stg;
     int fl;        // bit 0 in-domain, 1 owned, 2/3 element 0/1 inside the x-y update bounds, 4 (ODD) the pair
                    // of column nx-1 whose element 1 is the ghost, 6 the pair's parity: class of its element 0
@@ -385,7 +384,6 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     c.l0 = lo + HSTR * par;
     c.l1 = lo + HSTR - HSTR * par;
     c.ldo = q_.in ? (ghost ? gob - SZ : gob) : kDeadLane;
-    c.ldq = own ? c.ldo : kDeadLane;
     c.sto = (own && !ghost) ? gob : kDeadLane;
     c.stg = (own && ghost) ? gob : kDeadLane;
     scs[s] = c;
@@ -652,7 +650,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     if (MET) {
       const auto rp = rsrc_of(prev, pf, pf_st);
 #pragma unroll
-      for (int s = 0; s < (MET ? NS : 1); ++s) pvh[s] = ldp(rp, scs[s].ldq, ODD && (scs[s].fl & 16));
+      for (int s = 0; s < (MET ? NS : 1); ++s) pvh[s] = ldp(rp, __builtin_amdgcn_inverse_ballot_w64(mO[s]) ? scs[s].ldo : kDeadLane, ODD && (scs[s].fl & 16));
     }
     if (!RHS0) {
       const auto rr_ = rsrc_of(rhs, k + 1, k + 1 <= ke);
@@ -677,6 +675,16 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     // ZB: a stage plane of this step lies outside the z update bounds or on a mirror face (a handful of steps
     // per launch): those stages do not write / take the mirrored neighbour.  Stage planes that do not exist
     // (below plane 0, above the last plane) are outside the bounds.
+    // (the read-back goes through a copy of the address the compiler cannot see through: knowing that the word is the
+    // one the previous stage may have written, it forwards the written value in a register and reads LDS only in
+    // the lanes that did not write - a divergent if / else of five scalar instructions per update, in a kernel
+    // that is bound by instruction issue, to save one LDS read)
+    int zback[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      zback[s] = cL[s][HK];
+      if (RHS0) asm volatile("" : "+v"(zback[s]));   // (the kernels with an rhs window have no register to spare for it)
+    }
     auto stages = [&](auto ZBT) __attribute__((always_inline)) {
       constexpr bool ZB = decltype(ZBT)::value;
 #pragma unroll
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
         T oth[NS], xn[NS], yhv[NS], ylv[NS], zm[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          if (t > 0) zp[s] = LDSD(cL[s][HK] + NDSM_BO(t - 1));
+          if (t > 0) zp[s] = LDSD((RHS0 ? zback[s] : cL[s][HK]) + NDSM_BO(t - 1));
           oth[s] = LDSD(cL[s][1 - HK] + bB);
           xn[s] = LDSD(cX[s][HK] + bB);
           yhv[s] = LDSD(cYH[s][HK] + bB);
