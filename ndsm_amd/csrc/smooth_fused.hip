@@ -259,7 +259,15 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   const int x0 = tx * TXI - HX, y0 = ty * TYI - NSTG;
   const int zs = g.zown0 + cz * pl.zc;
   const int ze = min(zs + pl.zc, g.zown1);
-  const int ks = max(zs - NSTG, 0);
+  // first plane walked: NSTG warm-up planes below the chunk.  GROUPS: it is rounded DOWN to a multiple of the number
+  // of copies of the plane-step (below) and the loop runs whole groups of copies in a fixed order - no dispatch
+  // on k, no register shuffling where the copies meet (18 moves per step in the correction kernel) - at the
+  // price of up to NCOPY - 1 more steps at either end, which load nothing.  Not for the sweep + residual kernel:
+  // six copies there, and the pass is bound by memory, not by instructions.
+  constexpr int NCOPY = (NSTG % 2 == 0) ? NSTG : 2 * NSTG;
+  constexpr bool GROUPS = !RES;
+  const int kl = max(zs - NSTG, 0);        // first plane ever loaded
+  const int ks = GROUPS ? (kl / NCOPY) * NCOPY : kl;
   const int ke = min(ze - 1 + NSTG, nz - 1);  // last plane ever loaded
   const size_t sz = (size_t)nx * (size_t)ny;
   const int tid0 = (int)threadIdx.x;
@@ -293,8 +301,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 
 #define NDSM_LOAD_PLANE(base, k, dst)                                                                  \
   do {                                                                                                  \
-    const auto r_ = plane_rsrc((base) + sz * (size_t)(k), plane_bytes);                                 \
-    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) dst[s_] = ldp(r_, scs[s_].ldo, ODD && (scs[s_].fl & 16));     \
+    const auto r_ = rsrc_of(base, k, (k) >= kl && (k) <= ke);                                           \
+    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) dst[s_] = ldp(r_, scs[s_].ldo, ODD && (scs[s_].fl & 16)); \
   } while (0)
 
   // Register window per slot (everything else is re-read from LDS):
@@ -431,15 +439,13 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   // the kernel does not have - three 16-byte LDS reads per pair and plane instead
   double *const pwx = czt0 + 2 * CW * CH;
   double *const pwy = pwx + 4 * NPX;
-  int p_xa[PROL ? NS : 1], p_ya[PROL ? NS : 1];   // the slot's entries (element offsets)
+  int p_xa[PROL ? NS : 1], p_ya[PROL ? NS : 1];   // the slot's entries (byte offsets into the LDS)
   int cx0 = 0, cy0 = 0, kcur = 0;
-  // position of a pair in the parked coarse tile, packed into one register per slot: 4 * (row * CW + column of
-  // element 0's lower bracket) + (element 1's bracket column - element 0's + 1); the difference is 0 or 1 (-1 or 0
-  // for the odd-nx ghost)
-  int p_o[PROL ? NS : 1];
+  // where the lower-left corner of element 0's / element 1's bracket sits in the parked coarse tile (tile 0; byte
+  // offsets into the LDS): the other three corners and the second tile are immediate offsets from there
+  int p_c0[PROL ? NS : 1], p_c1[PROL ? NS : 1];
   double c_lo[NCS], c_hi[NCS], c_nx[NCS];
-  int c_off[NCS];   // (a coarse plane of the fused path's levels has far fewer than 2^31 points: launch_rbgs3_fused checks)
-  bool c_ok[NCS];
+  unsigned c_off[NCS];   // byte offset of the thread's coarse points inside a coarse plane (kDeadLane: outside the level)
   if (PROL) {
     const int ia = max(x0, 0), ja = max(y0, 0);
     cx0 = pa.plo[0][ia];
@@ -447,9 +453,10 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 #pragma unroll
     for (int s = 0; s < (PROL ? NS : 1); ++s) {
       const SlotT q(tid, s, x0, y0, nxs, ny);
-      p_o[s] = 1;
-      p_xa[s] = 4 * (q.li / 2);
-      p_ya[s] = 2 * q.lj;
+      const int czb = (int)(reinterpret_cast<char *>(czt0) - ldsb);
+      p_c0[s] = p_c1[s] = czb;
+      p_xa[s] = (int)(reinterpret_cast<char *>(pwx) - ldsb) + 32 * (q.live ? q.li / 2 : 0);
+      p_ya[s] = (int)(reinterpret_cast<char *>(pwy) - ldsb) + 16 * (q.live ? q.lj : 0);
       if (q.in) {
         const int jl = pa.plo[1][q.j] - cy0;
         int il[2];
@@ -458,7 +465,8 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
           const int ih = (ODD && q.i + h >= nx) ? q.i - 1 : q.i + h;   // the ghost gets column nx-2's correction
           il[h] = pa.plo[0][ih] - cx0;
         }
-        p_o[s] = 4 * (jl * CW + il[0]) + (il[1] - il[0] + 1);
+        p_c0[s] = czb + 8 * (jl * CW + il[0]);
+        p_c1[s] = czb + 8 * (jl * CW + il[1]);
       }
     }
     for (int t = tid; t < NPX + TYH; t += NT) {
@@ -482,28 +490,25 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     for (int c = 0; c < NCS; ++c) {
       const int idx = tid + NT * c;
       const int a = idx % CW, b = idx / CW;
-      c_ok[c] = b < CH && cx0 + a < pa.ncx && cy0 + b < pa.ncy;
-      c_off[c] = c_ok[c] ? (cx0 + a) + pa.ncx * (cy0 + b) : 0;
+      const bool c_ok = b < CH && cx0 + a < pa.ncx && cy0 + b < pa.ncy;
+      c_off[c] = c_ok ? (unsigned)((cx0 + a) + pa.ncx * (cy0 + b)) * 8u : kDeadLane;
       c_lo[c] = c_hi[c] = c_nx[c] = 0.0;
     }
   }
   const size_t csz = PROL ? (size_t)pa.ncx * (size_t)pa.ncy : 0;
-  // coarse planes kcur, kcur+1 (and, prefetched, kcur+2) of this thread's coarse points.  The loads are
-  // UNCONDITIONAL, from a clamped address, and what lies outside the coarse window is replaced by zero
-  // when the value is consumed: a load under a branch (or a select right behind it) is waited for on the
-  // spot, and the wait that consumes an OLDER load turns into vmcnt(0) as soon as a conditional load may
-  // have been issued in between - either way every coarse plane costs a full memory round trip on the
-  // critical path of the plane loop (measured: 803 us per launch against 531 us without the correction).
-  auto prol_plane_ok = [&](int kc) { return kc >= pa.ck0 && kc < pa.ck0 + pa.nczw; };
+  // coarse planes kcur, kcur+1 (and, prefetched, kcur+2) of this thread's coarse points: buffer loads through a
+  // descriptor per coarse plane - zero records for a plane outside the coarse window, an offset beyond the plane
+  // for a point outside the level, so that what must read as zero does, without a branch or a select (a load under
+  // a branch is waited for on the spot: measured 803 us per launch against 531 us without the correction)
+  const unsigned cbytes = PROL ? (unsigned)(csz * 8) : 0u;
   auto prol_load = [&](int kc, double *dst) {
-    const int kcl = min(max(kc, pa.ck0), pa.ck0 + pa.nczw - 1) - pa.ck0;
-    const double *pc = pa.uc + csz * (size_t)kcl;
+    const bool ok = kc >= pa.ck0 && kc < pa.ck0 + pa.nczw;
+    const auto rc_ = plane_rsrc(pa.uc + csz * (size_t)(ok ? kc - pa.ck0 : 0), ok ? cbytes : 0u);
 #pragma unroll
-    for (int c = 0; c < NCS; ++c) dst[c] = pc[c_off[c]];
-  };
-  auto prol_mask = [&](bool plane_ok, double *v) {
-#pragma unroll
-    for (int c = 0; c < NCS; ++c) v[c] = (plane_ok && c_ok[c]) ? v[c] : 0.0;
+    for (int c = 0; c < NCS; ++c) {
+      const v2u_t a_ = __builtin_amdgcn_raw_buffer_load_b64(rc_, c_off[c], 0, 0);
+      __builtin_memcpy(&dst[c], &a_, 8);
+    }
   };
   // advance the rolling coarse planes to the bracket of fine plane kf and park its z-interpolated
   // coarse plane in LDS (the caller puts a barrier between this and prol_corr)
@@ -548,7 +553,6 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     // ago at the latest; it is consumed (masked) here EVERY stage - taken over when the bracket moves,
     // dropped otherwise - and requested again right away, for the plane the next move will need
     const bool adv = kc > kcur;
-    prol_mask(prol_plane_ok(kcur + 2), c_nx);
 #pragma unroll
     for (int c = 0; c < NCS; ++c) {
       c_lo[c] = adv ? c_hi[c] : c_lo[c];
@@ -562,22 +566,22 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       if (idx < CW * CH) czt[idx] = whz * c_lo[c] + wlz * c_hi[c];  // last dimension first (ndsm_interp.f90:128-154)
     }
   };
-  // u + P u_c for this thread's pairs of the fine plane whose coarse plane is parked
-  auto prol_corr = [&](d2 *pl_, int kf) {
-    const double *const czt = czt0 + (kf & 1) * (CW * CH);
+  // u + P u_c for this thread's pairs of the fine plane whose coarse plane is parked in tile `tile` (kf & 1: a
+  // compile-time constant inside the plane-step).  Every LDS address is a per-slot register plus an immediate; a
+  // pair outside the domain has zero weights and holds +0: no predicate.
+  auto prol_corr = [&](d2 *pl_, const int tile) {
+    const int tb = tile * (CW * CH * 8);
 #pragma unroll
     for (int s = 0; s < (PROL ? NS : 1); ++s) {
-      if (!(scs[s].fl & 1)) continue;
-      const double *r0 = czt + (p_o[s] >> 2), *r1 = r0 + CW;
-      const double2 wy = *reinterpret_cast<const double2 *>(pwy + p_ya[s]);          // wl, wh of the row
-      const double2 wx0 = *reinterpret_cast<const double2 *>(pwx + p_xa[s]);         // wl, wh of element 0
-      const double2 wx1 = *reinterpret_cast<const double2 *>(pwx + p_xa[s] + 2);     // ... of element 1
+      const double2 wy = *reinterpret_cast<const double2 *>(ldsb + p_ya[s]);          // wl, wh of the row
+      const double2 wx0 = *reinterpret_cast<const double2 *>(ldsb + p_xa[s]);         // wl, wh of element 0
+      const double2 wx1 = *reinterpret_cast<const double2 *>(ldsb + p_xa[s] + 16);    // ... of element 1
       double v[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int il = h ? (p_o[s] & 3) - 1 : 0;
-        double f0 = r0[il], f1 = r0[il + 1];
-        const double f2 = r1[il], f3 = r1[il + 1];
+        const char *cq = ldsb + (h ? p_c1[s] : p_c0[s]) + tb;
+        double f0 = *reinterpret_cast<const double *>(cq), f1 = *reinterpret_cast<const double *>(cq + 8);
+        const double f2 = *reinterpret_cast<const double *>(cq + 8 * CW), f3 = *reinterpret_cast<const double *>(cq + 8 * CW + 8);
         f0 = wy.y * f0 + wy.x * f2;
         f1 = wy.y * f1 + wy.x * f3;
         v[h] = (h ? wx1.y : wx0.y) * f0 + (h ? wx1.x : wx0.x) * f1;
@@ -597,20 +601,18 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 #pragma unroll
       for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rw[s][0] = by_class(r0[s], s);
     }
-    if (ks + 1 <= ke) NDSM_LOAD_PLANE(u, ks + 1, nxt);
+    NDSM_LOAD_PLANE(u, ks + 1, nxt);
     if (PROL) {  // the two planes loaded here get their correction here
       kcur = pa.plo[2][min(max(ks + pa.fk0, 0), pa.nzf - 1)];
       prol_ztab(ks);
       prol_load(kcur, c_lo);
       prol_load(kcur + 1, c_hi);
       prol_load(kcur + 2, c_nx);
-      prol_mask(prol_plane_ok(kcur), c_lo);
-      prol_mask(prol_plane_ok(kcur + 1), c_hi);
       prol_stage(ks);
       if (ks + 1 <= ke) prol_stage(ks + 1);
       __syncthreads();
-      prol_corr(c0, ks);
-      if (ks + 1 <= ke) prol_corr(nxt, ks + 1);
+      prol_corr(c0, ks & 1);
+      if (ks + 1 <= ke) prol_corr(nxt, (ks + 1) & 1);
       __syncthreads();
       if (ks + 2 <= ke) prol_stage(ks + 2);  // for the first iteration; published by the barrier below
     }
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   const int zin0 = max(g.lb[2], 1 - g.k0), zin1 = min(g.ub[2], g.nzg - 2 - g.k0);
   // One plane-step.  The copy C of the step serves the iterations k = C (mod NCOPY): plane k-d sits in LDS buffer
   // (C - d) mod NB, every stage updates class C & 1.
-  constexpr int NCOPY = (NB % 2 == 0) ? NB : 2 * NB;
+  static_assert(NB == NSTG, "one LDS plane per pipeline stage");
   auto plane_step = [&](const int k, auto CT) __attribute__((always_inline)) {
     constexpr int C = decltype(CT)::value;
     constexpr int HK = C & 1;
@@ -653,12 +655,12 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       for (int s = 0; s < (MET ? NS : 1); ++s) pvh[s] = ldp(rp, __builtin_amdgcn_inverse_ballot_w64(mO[s]) ? scs[s].ldo : kDeadLane, ODD && (scs[s].fl & 16));
     }
     if (!RHS0) {
-      const auto rr_ = rsrc_of(rhs, k + 1, k + 1 <= ke);
+      const auto rr_ = rsrc_of(rhs, k + 1, k + 1 >= kl && k + 1 <= ke);
 #pragma unroll
       for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rn[s] = ldp(rr_, scs[s].ldo, ODD && (scs[s].fl & 16));
     }
     {
-      const auto ru = rsrc_of(u, k + 2, k + 2 <= ke);
+      const auto ru = rsrc_of(u, k + 2, k + 2 >= kl && k + 2 <= ke);
 #pragma unroll
       for (int s = 0; s < NS; ++s) nn[s] = ldp(ru, scs[s].ldo, ODD && (scs[s].fl & 16));
     }
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
 
     // PROL: the correction of the plane that arrived during the stages (its coarse plane was parked
     // one iteration ago), done here so that it overlaps with other waves' stages
-    if (PROL && k + 2 <= ke) prol_corr(nn, k + 2);
+    if (PROL && k + 2 <= ke) prol_corr(nn, C & 1);   // (k + 2 has the parity of k)
 
     // Plane pf has passed its last stage: it goes to HBM; the next step's last stage needs its class-(1-HK)
     // point.  DEFER: it is STORED only after the window shift below has consumed the loads of plane k+2: vmcnt
@@ -832,26 +834,34 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     __syncthreads();
 #undef NDSM_BO
   };
-  {
+  if constexpr (GROUPS) {
+    // (ks is a multiple of NCOPY.  The steps of the last group that lie beyond klast walk planes nobody stores and
+    // request planes beyond the chunk's last, which a descriptor of zero records answers with zeros.)
+#pragma unroll 1
+    for (int k = ks; k <= klast; k += NCOPY) {
+      plane_step(k, std::integral_constant<int, 0>());
+      plane_step(k + 1, std::integral_constant<int, 1>());
+      if constexpr (NCOPY > 2) {
+        plane_step(k + 2, std::integral_constant<int, 2 % NCOPY>());
+        plane_step(k + 3, std::integral_constant<int, 3 % NCOPY>());
+      }
+    }
+  } else {
     int kc = ks % NCOPY;   // which copy serves step k
 #pragma unroll 1
     for (int k = ks; k <= klast; ++k) {
-      // (exactly NCOPY copies of the step)
       if (kc == 0) {
         plane_step(k, std::integral_constant<int, 0>());
       } else if (kc == 1) {
         plane_step(k, std::integral_constant<int, 1>());
-      } else if constexpr (NCOPY > 2) {
-        if (kc == 2) {
-          plane_step(k, std::integral_constant<int, 2 % NCOPY>());
-        } else if (kc == 3) {
-          plane_step(k, std::integral_constant<int, 3 % NCOPY>());
-        } else if constexpr (NCOPY > 4) {
-          if (kc == 4)
-            plane_step(k, std::integral_constant<int, 4 % NCOPY>());
-          else
-            plane_step(k, std::integral_constant<int, 5 % NCOPY>());
-        }
+      } else if (kc == 2) {
+        plane_step(k, std::integral_constant<int, 2 % NCOPY>());
+      } else if (kc == 3) {
+        plane_step(k, std::integral_constant<int, 3 % NCOPY>());
+      } else if (kc == 4) {
+        plane_step(k, std::integral_constant<int, 4 % NCOPY>());
+      } else {
+        plane_step(k, std::integral_constant<int, 5 % NCOPY>());
       }
       kc = (kc + 1 == NCOPY) ? 0 : kc + 1;
     }
@@ -993,7 +1003,7 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
       const int zc = (nzo + c - 1) / c;
       const int cc = (nzo + zc - 1) / zc;
       const int64_t rounds = ((int64_t)tiles * cc + slots - 1) / slots;
-      const int64_t cost = rounds * (zc + 2 * NST);
+      const int64_t cost = rounds * (zc + 2 * NST + (RES ? 0 : NST - 1));
       if (best < 0 || cost < best) {
         best = cost;
         nzc = cc;
@@ -1183,7 +1193,7 @@ int launch_rbgs3_fused(const ndsmk_grid &g, const double *u, double *uout, const
     pa.ck0 = px->c_k0;
     pa.nczw = (px->f_k0 == 0 && px->c_k0 == 0 && px->nf[2] == g.n[2]) ? px->nc[2] : px->c_cnt;
     if (px->f_k0 != g.k0 || px->nf[0] != g.n[0] || px->nf[1] != g.n[1] || px->nf[2] != g.nzg || pa.nczw < 1 ||
-        (int64_t)pa.ncx * pa.ncy >= ((int64_t)1 << 31)) {
+        (int64_t)pa.ncx * pa.ncy * 8 >= (int64_t)kDeadLane) {   // (a coarse plane is addressed with 32-bit byte offsets)
       *sweeps_done = 0;
       return 0;
     }
