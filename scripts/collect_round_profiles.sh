@@ -19,7 +19,12 @@ scripts/pmc_kernel.sh ${tag}_rs2 restrict_stream2_k -- scripts/time_transfer.py 
 cp gpurun_out/pmc_${tag}_rs2/summary.txt $out/${tag}_restrict_stream2_counters.txt
 NDSM_RS_VARIANT=0 scripts/pmc_kernel.sh ${tag}_rs0 restrict_stream_k -- scripts/time_transfer.py 512 > /dev/null
 cp gpurun_out/pmc_${tag}_rs0/summary.txt $out/${tag}_restrict_stream_v0_counters.txt
+# the dominant launch (two-sweep Laplace pass of level 1) and the correction launch: instruction mix, waits, LDS
+scripts/pmc_kernel.sh ${tag}_s2 "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, true, 0, true, false>" -- scripts/run_sweeps.py 512 7 zero > /dev/null
+cp gpurun_out/pmc_${tag}_s2/summary.txt $out/${tag}_smoother_s2_counters.txt
+scripts/pmc_kernel.sh ${tag}_prol "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, true, 3, false, false>" -- scripts/cycle_trace.py 512 > /dev/null
+cp gpurun_out/pmc_${tag}_prol/summary.txt $out/${tag}_smoother_correction_counters.txt
 echo "counters done"
-python3 scripts/time_pipeline.py 512 > $out/pipeline.log 2>&1 || true
+python3 scripts/time_pipeline.py 512 > $out/${tag}_pipeline_phases.txt 2>&1 || true
 python3 scripts/time_tail.py 512 > $out/${tag}_levels.txt 2>&1 || true
 ls -la $out
