@@ -634,6 +634,17 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
   // One plane-step.  The copy C of the step serves the iterations k = C (mod NCOPY): plane k-d sits in LDS buffer
   // (C - d) mod NB, every stage updates class C & 1.
   static_assert(NB == NSTG, "one LDS plane per pipeline stage");
+  // Running addresses of the planes a step touches - plane k+2 of u, k+1 of rhs, pf of uout / prev, pf-1 of rout -
+  // advanced by one plane at the end of every step: two scalar additions per array instead of a 64-bit multiply
+  // and its carries (the descriptors were a third of the scalar instructions of a step).  An address outside its
+  // array belongs to a plane outside its window: the descriptor then has zero records and nothing is accessed.
+  const long long pbs = (long long)sz * SZ;
+  const char *a_ld = reinterpret_cast<const char *>(u) + pbs * (ks + 2);
+  const char *a_rh = RHS0 ? nullptr : reinterpret_cast<const char *>(rhs) + pbs * (ks + 1);
+  const char *a_pv = MET ? reinterpret_cast<const char *>(prev) + pbs * (ks - (NST - 1)) : nullptr;
+  char *a_st = reinterpret_cast<char *>(uout) + pbs * (ks - (NST - 1));
+  char *a_rs = RES ? reinterpret_cast<char *>(rout) + pbs * (ks - NST) : nullptr;
+  auto rsrc_at = [&](const void *at, bool ok) { return plane_rsrc(at, ok ? plane_bytes : 0u); };
   auto plane_step = [&](const int k, auto CT) __attribute__((always_inline)) {
     constexpr int C = decltype(CT)::value;
     constexpr int HK = C & 1;
@@ -650,17 +661,17 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
     // MET: the previous iterate of plane pf; plane k+1 of rhs; plane k+2 of u - requested before plane k is touched
     d2 pvh[MET ? NS : 1];
     if (MET) {
-      const auto rp = rsrc_of(prev, pf, pf_st);
+      const auto rp = rsrc_at(a_pv, pf_st);
 #pragma unroll
       for (int s = 0; s < (MET ? NS : 1); ++s) pvh[s] = ldp(rp, __builtin_amdgcn_inverse_ballot_w64(mO[s]) ? scs[s].ldo : kDeadLane, ODD && (scs[s].fl & 16));
     }
     if (!RHS0) {
-      const auto rr_ = rsrc_of(rhs, k + 1, k + 1 >= kl && k + 1 <= ke);
+      const auto rr_ = rsrc_at(a_rh, k + 1 >= kl && k + 1 <= ke);
 #pragma unroll
       for (int s = 0; s < (RHS0 ? 1 : NS); ++s) rn[s] = ldp(rr_, scs[s].ldo, ODD && (scs[s].fl & 16));
     }
     {
-      const auto ru = rsrc_of(u, k + 2, k + 2 >= kl && k + 2 <= ke);
+      const auto ru = rsrc_at(a_ld, k + 2 >= kl && k + 2 <= ke);
 #pragma unroll
       for (int s = 0; s < NS; ++s) nn[s] = ldp(ru, scs[s].ldo, ODD && (scs[s].fl & 16));
     }
@@ -776,11 +787,11 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
       }
     }
     if (!DEFER) {   // (planes outside the store window: a descriptor of zero records, nothing is written)
-      const auto rs_ = rsrc_of(uout, pf, pf_st);
+      const auto rs_ = rsrc_at(a_st, pf_st);
 #pragma unroll
       for (int s = 0; s < NS; ++s) stp(rs_, scs[s].sto, scs[s].stg, finh[s]);
       if (RES) {
-        const auto rr_ = rsrc_of(rout, pr, pr_st);
+        const auto rr_ = rsrc_at(a_rs, pr_st);
 #pragma unroll
         for (int s = 0; s < NS; ++s) stp(rr_, scs[s].sto, scs[s].stg, resh[RES ? s : 0]);
       }
@@ -826,11 +837,16 @@ __global__ __launch_bounds__(NT, WPS) void rbgs3_fused_k(const T *__restrict__ u
         }
       }
       {
-        const auto rs_ = rsrc_of(uout, pf, pf_st);
+        const auto rs_ = rsrc_at(a_st, pf_st);
 #pragma unroll
         for (int s = 0; s < NS; ++s) stp(rs_, scs[s].sto, scs[s].stg, finh[s]);
       }
     }
+    a_ld += pbs;
+    a_st += pbs;
+    if (!RHS0) a_rh += pbs;
+    if (MET) a_pv += pbs;
+    if (RES) a_rs += pbs;
     __syncthreads();
 #undef NDSM_BO
   };
@@ -1090,13 +1106,21 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   // prev != nullptr: the launch that performs the last of the max_sweeps sweeps also evaluates
   // the convergence metric against prev (fp64, single domain; *met_done says it did)
   const bool met = std::is_same<T, double>::value && prev && met_done;
-  // prol != nullptr: u + P u_c is to be formed while the planes are loaded (MODE 3).  Built for
-  // the two-sweep Laplace launch only; if this call cannot be that launch NOTHING is launched
-  // (*sweeps_done = 0) and the caller interpolates with the stand-alone kernel first.
+  // prol != nullptr: u + P u_c is to be formed while the planes are loaded (MODE 3).  Built for Laplace
+  // problems only (launch_cfg); if this call cannot be such a launch NOTHING is launched (*sweeps_done = 0) and
+  // the caller interpolates with the stand-alone kernel first.
+  // The interpolation costs ~100 instructions per plane-step and wave.  On top of a TWO-sweep pass - which is bound
+  // by instruction issue with it - that is +240 us at 512^3 (720 against 480); a ONE-sweep pass has the issue
+  // slots to spare (it is bound by memory: 430 us).  So an odd number of sweeps (NDSM's ms = 5) is taken as
+  // 1 + 2 + 2 with the correction on the one-sweep pass - the sweeps that remain are two-sweep passes, the last
+  // of which carries the convergence metric - instead of 2 + 2 + 1.
   if (prol) {
     if constexpr (std::is_same<T, double>::value) {
-      // (Laplace problems only - launch_cfg)
-      if (!rhs && two && !(met && max_sweeps == 2) && cfg[0] == 0) {
+      if (!rhs && cfg[0] == 0 && !slab && (max_sweeps & 1) && max_sweeps >= 3) {
+        rc = (launch_cfg<T, 1, 132, 31, 1024, 4, 3, false, ODD>(g, u, uout, rhs, tgt, nullptr, nullptr, prol));
+        if (rc) return rc;
+        *sweeps_done = 1;
+      } else if (!rhs && two && !(met && max_sweeps == 2) && cfg[0] == 0) {
         rc = (launch_cfg<T, 2, 136, 30, 1024, 4, 3, false, ODD>(g, u, uout, rhs, tgt, nullptr, nullptr, prol));
         if (rc) return rc;
         *sweeps_done = 2;
