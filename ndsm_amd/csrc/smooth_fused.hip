@@ -1116,7 +1116,7 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   // of which carries the convergence metric - instead of 2 + 2 + 1.
   if (prol) {
     if constexpr (std::is_same<T, double>::value) {
-      if (!rhs && cfg[0] == 0 && !slab && (max_sweeps & 1) && max_sweeps >= 3) {
+      if (!rhs && cfg[0] == 0 && (max_sweeps & 1) && (max_sweeps >= 3 || slab)) {   // (a slab window asks for exactly its pass)
         rc = (launch_cfg<T, 1, 132, 31, 1024, 4, 3, false, ODD>(g, u, uout, rhs, tgt, nullptr, nullptr, prol));
         if (rc) return rc;
         *sweeps_done = 1;

@@ -586,9 +586,12 @@ contains
     do while (left > 0)
       n = 1
       if (two_ok .and. left >= 2 .and. .not. (res .and. left == 2)) n = 2
+      ! an odd number of sweeps that starts with the correction: 1 + 2 + 2 ..., the correction on the ONE-sweep
+      ! pass (bound by memory, it has the instruction slots the interpolation needs; a two-sweep pass does not)
+      if (pend .and. .not. res .and. left >= 3 .and. mod(left, 2) == 1) n = 1
       pro = .false.
       if (pend) then
-        pro = n == 2 .and. .not. (res .and. left == 1)
+        pro = .not. (res .and. left == 1)
         do i = 1, w%nlocal
           pro = pro .and. mg_window_prolong_ok(w%loc(i), n)
         end do
