@@ -486,7 +486,7 @@ extern "C" int ndsmk_fused_window_res(const ndsmk_grid *gp, const double *u, dou
 // can ndsmk_fused_window(..., prev) evaluate the metric? (fp64 level off the all-Neumann path)
 extern "C" int ndsmk_fused_metric_ok(const ndsmk_grid *gp) { return (gp->ndim == 3 && !gp->all_neumann) ? 1 : 0; }
 
-// can ndsmk_fused_window(..., px, uc) interpolate while it loads? (one or two sweeps, no right-hand side, fp64)
+// can ndsmk_fused_window(..., px, uc) interpolate while it loads? (one sweep, or two without a right-hand side; fp64)
 extern "C" int ndsmk_fused_prolong_ok(const ndsmk_grid *gp, const double *rhs, int nsweeps) {
-  return (gp->ndim == 3 && !rhs && (nsweeps == 1 || nsweeps == 2) && !gp->all_neumann) ? 1 : 0;
+  return (gp->ndim == 3 && (!rhs || nsweeps == 1) && (nsweeps == 1 || nsweeps == 2) && !gp->all_neumann) ? 1 : 0;
 }

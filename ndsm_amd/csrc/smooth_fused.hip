@@ -984,10 +984,12 @@ int launch_cfg(const ndsmk_grid &g, const T *u, T *uout, const T *rhs, int targe
                            (MODE == 3 ? sizeof(double) * (2 * (TXH / 2 + 3) * (TYH / 2 + 3) + 2 * TXH + 2 * TYH) : 0);
   static int attr_epoch[2] = {0, 0};   // per instantiation and device epoch (ndsmk_init may re-target)
   static int wgs_per_cu[2] = {1, 1};
-  // The correction mode exists for the declared-zero right-hand side only: with a right-hand-side window on top of
-  // the interpolation state the kernel does not fit 128 registers (round 3, weights already in LDS: 124 bytes of
-  // scratch per lane), and a Poisson cycle is faster with the stand-alone interpolation in front.
-  constexpr bool GEN = MODE != 3;   // is there an instantiation that reads rhs?
+  // The TWO-sweep correction launch exists for the declared-zero right-hand side only: with a right-hand-side
+  // window on top of the interpolation state it does not fit 128 registers (round 3, weights already in LDS: 124
+  // bytes of scratch per lane).  The ONE-sweep one carries a right-hand side too (52 bytes of scratch per lane,
+  // outside the plane loop's steady state; 512^3 Poisson cycle 6.83 -> 6.41 ms against the stand-alone
+  // interpolation in front of the sweeps).
+  constexpr bool GEN = MODE != 3 || S == 1;   // is there an instantiation that reads rhs?
   if (!GEN && rhs) return ndsm::fail(NDSMK_EARG, "the correction launch is built for rhs == 0 only", __FILE__, __LINE__);
   using KF = void (*)(const T *, T *, const T *, T *, const T *, double *, ndsmk_grid, FusedPlan, ProlArgs);
   KF kgen = nullptr;
@@ -1106,9 +1108,9 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   // prev != nullptr: the launch that performs the last of the max_sweeps sweeps also evaluates
   // the convergence metric against prev (fp64, single domain; *met_done says it did)
   const bool met = std::is_same<T, double>::value && prev && met_done;
-  // prol != nullptr: u + P u_c is to be formed while the planes are loaded (MODE 3).  Built for Laplace
-  // problems only (launch_cfg); if this call cannot be such a launch NOTHING is launched (*sweeps_done = 0) and
-  // the caller interpolates with the stand-alone kernel first.
+  // prol != nullptr: u + P u_c is to be formed while the planes are loaded (MODE 3): a one-sweep pass (any
+  // right-hand side) or a two-sweep pass (rhs == 0 only).  If this call cannot be such a launch NOTHING is launched
+  // (*sweeps_done = 0) and the caller interpolates with the stand-alone kernel first.
   // The interpolation costs ~100 instructions per plane-step and wave.  On top of a TWO-sweep pass - which is bound
   // by instruction issue with it - that is +240 us at 512^3 (720 against 480); a ONE-sweep pass has the issue
   // slots to spare (it is bound by memory: 430 us).  So an odd number of sweeps (NDSM's ms = 5) is taken as
@@ -1116,7 +1118,7 @@ static int launch_fused_t(const ndsmk_grid &g, const T *u, T *uout, const T *rhs
   // of which carries the convergence metric - instead of 2 + 2 + 1.
   if (prol) {
     if constexpr (std::is_same<T, double>::value) {
-      if (!rhs && cfg[0] == 0 && (max_sweeps & 1) && (max_sweeps >= 3 || slab)) {   // (a slab window asks for exactly its pass)
+      if (cfg[0] == 0 && (max_sweeps & 1) && (max_sweeps >= 3 || slab)) {   // (a slab window asks for exactly its pass)
         rc = (launch_cfg<T, 1, 132, 31, 1024, 4, 3, false, ODD>(g, u, uout, rhs, tgt, nullptr, nullptr, prol));
         if (rc) return rc;
         *sweeps_done = 1;

@@ -750,7 +750,7 @@ contains
     ok = ndsmk_fused_metric_ok(s%lev(1)%g) /= 0
   end function
 
-  ! can a pass of n sweeps over this slab fold the prolongation in? (two sweeps, Laplace problem)
+  ! can a pass of n sweeps over this slab fold the prolongation in? (one sweep, or two on a Laplace problem)
   function mg_window_prolong_ok(s, n) result(ok)
     type(mg_solver), intent(in) :: s
     integer, intent(in) :: n

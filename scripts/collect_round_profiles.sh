@@ -22,7 +22,7 @@ cp gpurun_out/pmc_${tag}_rs0/summary.txt $out/${tag}_restrict_stream_v0_counters
 # the dominant launch (two-sweep Laplace pass of level 1) and the correction launch: instruction mix, waits, LDS
 scripts/pmc_kernel.sh ${tag}_s2 "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, true, 0, true, false>" -- scripts/run_sweeps.py 512 7 zero > /dev/null
 cp gpurun_out/pmc_${tag}_s2/summary.txt $out/${tag}_smoother_s2_counters.txt
-scripts/pmc_kernel.sh ${tag}_prol "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, true, 3, false, false>" -- scripts/cycle_trace.py 512 > /dev/null
+scripts/pmc_kernel.sh ${tag}_prol "rbgs3_fused_k<double, 1, 132, 31, 1024, 4, true, 3, false, false>" -- scripts/cycle_trace.py 512 > /dev/null
 cp gpurun_out/pmc_${tag}_prol/summary.txt $out/${tag}_smoother_correction_counters.txt
 echo "counters done"
 python3 scripts/time_pipeline.py 512 > $out/${tag}_pipeline_phases.txt 2>&1 || true

@@ -1599,3 +1599,25 @@ def test_correction_launch_with_one_tall_chunk(hip, port):
         L.ndsm_hip_debug_fused_cfg(0, 0, 0, 0, -1)
     assert nc == nc2 == 2 and list(h) == list(h2[:2])
     assert np.array_equal(got, u2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns", [[136, 130, 140], [131, 140, 134]])
+def test_correction_launch_with_rhs_vs_oracle(hip, port, ns):
+    """a Poisson problem (right-hand side in HBM) takes its correction on the one-sweep launch that opens the
+    post-smoothing (rbgs3_fused_k<.., S = 1, .., RHS0 = false, MODE = 3>): three solve-loop cycles, even and odd
+    nx, several tiles and chunks, against the oracle - field, du history and cycle count
+    (ndsm_multigrid_core.f90:593-684 coarse_to_fine followed by :672-675's sweeps)"""
+    mesh = uniform_mesh(ns)
+    shp = tuple(ns[::-1])
+    u0 = rand_field(shp, 41)
+    rhs = rand_field(shp, 42) * 50.0
+    ie2, u2, du2, h2, nc2, _sw = port.solve_bvp(u0.copy(), rhs, mesh, "NDDNDD", ms=5, nmax=3, hist_len=4)
+    S = hip.MGSolver(ns, mesh, "NDDNDD", ms=5)
+    S.upload(1, hip.BUF_RHS, rhs)
+    S.upload(1, hip.BUF_U, u0)
+    ie, du, nc, h = S.solve(vc_tol=1e-30, nmax=3, hist_len=4)
+    got = S.download(1, hip.BUF_U)
+    S.close()
+    assert nc == nc2 == 3 and list(h) == list(h2[:3])
+    assert np.array_equal(got, u2)
