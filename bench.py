@@ -100,6 +100,50 @@ def spawn_ranks(args):
     return rc
 
 
+EXIT_OVERLAP_HUNG = 17     # a worker's way of saying: the overlapped exchange never came back - start me again without it
+
+
+def supervise_rank():
+    """A rank of an N > 1 job does its work in a CHILD process and only watches it.  The overlapped halo
+    exchange (one RCCL communicator driven from two streams) has met real multi-GPU hardware in no run this
+    repository could make; should it wedge, a process that already holds the GPU cannot fall back by itself -
+    its streams are stuck behind the collective.  The worker's watchdog ends it with EXIT_OVERLAP_HUNG instead,
+    every rank's supervisor sees that, and all of them start a second worker with NDSM_HIP_OVERLAP=0 (exchange
+    on the main stream) on a rendezvous of its own.  This process never loads the library or touches a GPU."""
+    import subprocess
+    rc = 3
+    for attempt in (0, 1):
+        env = dict(os.environ, NDSM_BENCH_WORKER="1", NDSM_BENCH_ATTEMPT=str(attempt))
+        if attempt == 1:
+            env["NDSM_HIP_OVERLAP"] = "0"
+            # (its rendezvous is a store rank 0's worker hosts: with this set, torch would look for the launcher's)
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
+        if rc != EXIT_OVERLAP_HUNG:
+            break
+        print(f"bench.py[rank {os.environ.get('RANK', '?')}]: the worker gave up on the overlapped exchange" +
+              (": starting it again with NDSM_HIP_OVERLAP=0" if attempt == 0 else " twice"), file=sys.stderr, flush=True)
+    return rc
+
+
+class Watchdog:
+    """ends THIS process with `code` unless cancelled within `seconds` (a wedged collective cannot be interrupted)"""
+
+    def __init__(self, seconds, code, what):
+        import threading
+
+        def fire():
+            print(f"bench.py[rank {os.environ.get('RANK', '?')}]: {what} did not finish within {seconds:.0f} s - "
+                  f"exit {code}", file=sys.stderr, flush=True)
+            os._exit(code)
+        self.t = threading.Timer(seconds, fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def cancel(self):
+        self.t.cancel()
+
+
 def boundary_problem(n):
     """Ax of the analytic field (integration_test1.py:57-99) on the four
     Dirichlet faces of the Ax problem ("NDDNDD"), zero elsewhere, rhs = 0."""
@@ -455,6 +499,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # a lone process asked for N GPUs: it becomes the launcher of N ranks (one process per GPU)
         raise SystemExit(spawn_ranks(args))
+    if args.gpus > 1 and not os.environ.get("NDSM_BENCH_WORKER"):
+        raise SystemExit(supervise_rank())
+    attempt = int(os.environ.get("NDSM_BENCH_ATTEMPT", "0"))
 
     # ONE JSON line on stdout: everything else this process and the native libraries under it write to
     # file descriptor 1 (the reference's and our Fortran `PRINT *` warnings, flushed at exit) goes to
@@ -501,7 +548,13 @@ def main():
             # one node by contract: the CPU rendezvous / control traffic stays on the loop-back interface
             # (gloo otherwise picks the interface the host NAME resolves to - which it may not)
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        if attempt == 0:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            # second worker of this rank: a store of its own (rank 0 hosts it), not the launcher's, which still holds
+            # the first worker's keys
+            port2 = 20000 + (int(os.environ.get("MASTER_PORT", "29500")) + 7919) % 20000
+            dist.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{port2}", rank=rank, world_size=world)
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             uid = torch.frombuffer(bytearray(_lib.dist_unique_id(L)), dtype=torch.uint8).clone()
@@ -525,6 +578,7 @@ def main():
             dist.barrier()
 
     ms = args.ms
+    timed_dog = None
     if world == 1:
         n = args.n
         n3 = [n, n, n]
@@ -558,10 +612,21 @@ def main():
         # the distributed path against the single-GPU solver on the real transport, bit for bit - with the
         # halo exchange on the main stream and (forced) on the second stream behind the interior planes
         checks = []
+        hang_s = float(os.environ.get("NDSM_BENCH_OVERLAP_TIMEOUT", "180"))
         for ov in ("0", "1"):
+            if ov == "1" and attempt > 0:
+                checks.append("MISMATCH: the overlapped exchange did not come back within "
+                              f"{hang_s:.0f} s in this job's first worker; not tried again")
+                continue
+            # from here until the timed region is over a wedged overlapped exchange ends this worker with
+            # EXIT_OVERLAP_HUNG (supervise_rank starts the next one without the overlap)
+            if ov == "1":
+                overlap_dog = Watchdog(hang_s, EXIT_OVERLAP_HUNG, "the overlapped self-check")
             old = os.environ.get("NDSM_HIP_OVERLAP")
             os.environ["NDSM_HIP_OVERLAP"] = ov
             try:
+                if ov == "1" and os.environ.get("NDSM_BENCH_FAKE_HANG"):   # (tests/test_gpu_multirank.py)
+                    time.sleep(1e6)
                 checks.append(slab_self_check(_lib, L, dist, rank, world))
             except Exception as exc:  # noqa: BLE001
                 checks.append(f"MISMATCH: self-check could not run: {type(exc).__name__}: {exc}")
@@ -574,6 +639,8 @@ def main():
         verdict = [checks if rank == 0 else None]
         dist.broadcast_object_list(verdict, 0)
         checks = verdict[0]
+        if attempt == 0:
+            overlap_dog.cancel()
         all_ok("MISMATCH" not in checks[0], "slab self-check against the single-GPU solver (exchange on the main stream)", checks[0])
         slab_check = checks[0] + " [exchange on the main stream]; " + checks[1] + " [exchange overlapped]"
         if "MISMATCH" in checks[1]:
@@ -581,6 +648,8 @@ def main():
             # single-stream one is right: time THAT - still the z-slab RCCL path - and say so
             os.environ["NDSM_HIP_OVERLAP"] = "0"
             slab_check += "; TIMED WITH NDSM_HIP_OVERLAP=0 (single-stream exchange) because the overlapped self-check failed"
+        if attempt == 0 and os.environ.get("NDSM_HIP_OVERLAP", "1") != "0":
+            timed_dog = Watchdog(300.0, EXIT_OVERLAP_HUNG, "the z-slab world's set-up and timed region with the overlapped exchange")
         n3 = [int(v) for v in args.slab_shape.split(",")]
         x = np.linspace(0.0, 1.0, n3[0])
         dx = x[1] - x[0]
@@ -620,6 +689,8 @@ def main():
         t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t[0])
+    if timed_dog is not None:
+        timed_dog.cancel()
     ms_per_step = el / args.steps * 1e3
 
     # ---- dominant kernel: the level-1 smoother launches under HIP events on the library stream ----

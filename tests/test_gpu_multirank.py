@@ -240,3 +240,25 @@ def test_bench_lone_process_starts_its_own_ranks(hip):
     assert "MISMATCH" not in out["slab_check"], out["slab_check"]
     assert "REHEARSAL SHAPE" in out["config"]["workload"]
     assert out["roofline"]["frac"] is None and out["roofline"]["frac_algorithmic"] > 0     # no counter figure in slab mode
+
+
+@pytest.mark.gpu
+def test_bench_restarts_without_overlap_when_the_overlapped_exchange_wedges(hip):
+    """a wedged overlapped exchange (simulated: the first worker of every rank never returns from its overlapped
+    self-check) must still end in a result line: each rank's watchdog ends its worker, each rank's supervisor
+    starts a second one with NDSM_HIP_OVERLAP=0 on a rendezvous of its own, and the line says which schedule was
+    timed.  Two ranks on the test double."""
+    env = dict(os.environ, NDSM_HIP_LIB=_fake(), FAKE_RCCL_TIMEOUT="120", FAKE_RCCL_SLOT_MB="64",
+               NDSM_BENCH_FAKE_HANG="1", NDSM_BENCH_OVERLAP_TIMEOUT="8")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NDSM_HIP_OVERLAP"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--slab-shape", "128,128,192", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["slab_mode"] is True and out["rccl_ranks"] == 2
+    assert "TIMED WITH NDSM_HIP_OVERLAP=0" in out["slab_check"] and "did not come back" in out["slab_check"]
+    assert "starting it again with NDSM_HIP_OVERLAP=0" in r.stderr
