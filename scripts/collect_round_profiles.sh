@@ -15,10 +15,11 @@ echo "bench done"
 bash scripts/collect_traffic.sh > $out/traffic.log 2>&1 || true
 cp profiles/traffic_latest.json $out/traffic_latest.json
 echo "traffic done"
-scripts/pmc_kernel.sh ${tag}_rs2 restrict_stream2_k -- scripts/time_transfer.py 512 > /dev/null
-cp gpurun_out/pmc_${tag}_rs2/summary.txt $out/${tag}_restrict_stream2_counters.txt
-NDSM_RS_VARIANT=0 scripts/pmc_kernel.sh ${tag}_rs0 restrict_stream_k -- scripts/time_transfer.py 512 > /dev/null
-cp gpurun_out/pmc_${tag}_rs0/summary.txt $out/${tag}_restrict_stream_v0_counters.txt
+# the level-1 restriction: the default (DMA) form and the register-staged form it replaced
+scripts/pmc_kernel.sh ${tag}_rs "restrict_stream_k<double, 64, 8, 5, 64, 4, false, true, true>" -- scripts/time_transfer.py 512 > /dev/null
+cp gpurun_out/pmc_${tag}_rs/summary.txt $out/${tag}_restrict_counters.txt
+NDSM_RS_VARIANT=8 scripts/pmc_kernel.sh ${tag}_rs8 "restrict_stream_k<double, 64, 8, 5, 64, 4, false, true, false>" -- scripts/time_transfer.py 512 > /dev/null
+cp gpurun_out/pmc_${tag}_rs8/summary.txt $out/${tag}_restrict_staged_form_counters.txt
 # the dominant launch (two-sweep Laplace pass of level 1) and the correction launch: instruction mix, waits, LDS
 scripts/pmc_kernel.sh ${tag}_s2 "rbgs3_fused_k<double, 2, 136, 30, 1024, 4, true, 0, true, false>" -- scripts/run_sweeps.py 512 7 zero > /dev/null
 cp gpurun_out/pmc_${tag}_s2/summary.txt $out/${tag}_smoother_s2_counters.txt
