@@ -984,7 +984,8 @@ contains
       do l = 1, nl
         if (.not. active(l)) cycle
         rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800
-        if (graphs(l) .and. it >= 2) then
+        ! (a cycle recorded by an earlier call and still valid is replayed from the first round on)
+        if (graphs(l) .and. (it >= 2 .or. graph_valid(ss(l), l - 1))) then
           if (.not. graph_valid(ss(l), l - 1)) then
             call drop_graph(ss(l))
             rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800   ! (drop_graph drains the device only)

@@ -113,7 +113,7 @@ contains
       rc = ndsmk_sync()
       call system_clock(c, r)
       t = real(c, wp) / real(r, wp)
-      write (error_unit, '(A,F9.3,A)') "TIMING(+", t - t_last, " s) before: "//what
+      write (error_unit, '(A,F12.6,A)') "TIMING(+", t - t_last, " s) before: "//what
       t_last = t
     end if
     if (verbose) write (error_unit, '(A)') "DEBUG("//where//"):"//what
