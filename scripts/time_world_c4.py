@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, ndsm_amd
 from ndsm_amd import _lib
 L = ndsm_amd.load_library(); assert L.ndsm_hip_init(0) == 0
-ns = [1024, 1024, 512]; nr = 8
+ns = [1024, 1024, 512]; nr = int(os.environ.get("NR", "8"))
 dx = 1.0 / (ns[0] - 1); mesh = [np.arange(n) * dx for n in ns]
 u = np.random.default_rng(11).uniform(-1, 1, (ns[2], 1, 1)) * np.ones((1, ns[1], ns[0]))
 for ov in ("1", "0"):
