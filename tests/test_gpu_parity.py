@@ -1575,6 +1575,52 @@ def test_vecpot_paths_small_and_ragged_shapes(hip, port, ns):
     assert np.abs(B0 - Bo).max() <= 1e-12 * max(np.abs(Ao).max(), 1e-300) * 4 / h
 
 
+_RESTRICT_FORMS_CHILD = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, ndsm_amd
+from ndsm_amd import _lib
+from golden_inputs import rand_field, uniform_mesh
+L = ndsm_amd.load_library(); assert L.ndsm_hip_init(0) == 0
+out = {}
+for ns, bcs in (([200, 150, 220], "NDDNDD"), ([201, 150, 216], "DNNDDN"), ([320, 140, 150], "DDDDDD")):
+    S = _lib.MGSolver(ns, uniform_mesh(ns), bcs)
+    S.upload(1, _lib.BUF_R, rand_field(tuple(ns[::-1]), 77))
+    S.upload(2, _lib.BUF_U, np.full(S._npshape(2), 3.0))
+    S.op(_lib.OP_RESTRICT, 1)
+    rc, uc = S.download(2, _lib.BUF_RHS), S.download(2, _lib.BUF_U)
+    out["x".join(map(str, ns))] = [hashlib.sha256(rc.tobytes()).hexdigest(), bool(uc.any())]
+    S.close()
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+def test_restriction_forms_agree():
+    """the three forms of the streamed restriction (restrict_stream.hip: NDSM_RS_VARIANT = 10 fine planes by LDS-DMA +
+    schedule + ordered accumulators, the default for fp64 levels with even nx; 8 register-staged with the schedule;
+    5 register-staged with the table walk) and the gather kernel (NDSM_HIP_NO_STREAM_RESTRICT) on the same residual
+    fields - even and odd nx, three BC sets: the same coarse right-hand side bit for bit, coarse u zeroed
+    (nrestrict, ndsm_interp.f90:263-290; ndsm_multigrid_core.f90:557-558).  The variant is read once per process:
+    one child per form."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("gather", {"NDSM_HIP_NO_STREAM_RESTRICT": "1"}), ("dma", {"NDSM_RS_VARIANT": "10"}),
+                     ("staged+schedule", {"NDSM_RS_VARIANT": "8"}), ("staged+walk", {"NDSM_RS_VARIANT": "5"})):
+        e = dict(os.environ, **env)
+        if tag != "gather":
+            e.pop("NDSM_HIP_NO_STREAM_RESTRICT", None)
+        r = subprocess.run([sys.executable, "-c", _RESTRICT_FORMS_CHILD, ROOT], env=e, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for tag in ("dma", "staged+schedule", "staged+walk"):
+        assert res[tag] == res["gather"], (tag, res[tag], res["gather"])
+    assert not any(v[1] for v in res["gather"].values())
+
+
 @pytest.mark.gpu
 def test_correction_launch_with_one_tall_chunk(hip, port):
     """the launch that interpolates the coarse-grid correction while it loads (MODE 3) keeps the z tables of
