@@ -167,43 +167,74 @@ __global__ __launch_bounds__(1024) void rbgs2_medium(double *__restrict__ u_g, c
                                                      ndsmk_grid g, int nsweeps) {
   extern __shared__ __attribute__((aligned(16))) double u[];  // the whole level
   __shared__ double red[16];
+  constexpr int KQ = 8;   // points per thread and colour held in registers (128^2: exactly these; more: the loop below)
   const int nx = g.n[0], ny = g.n[1];
   const int n = nx * ny;
   for (int p = threadIdx.x; p < n; p += blockDim.x) u[p] = u_g[p];
-  __syncthreads();
   const int mx = g.ub[0] - g.lb[0] + 1, my = g.ub[1] - g.lb[1] + 1;
   const int half = (mx + 1) / 2;
   const int total = half * my;
+  // one point of the colour pass `par`: ndsm_poisson.f90:603-617, mirror faces folded into the neighbour index
+  auto update = [&](int i, int j, double r) {
+    const int xl = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i - 1);
+    const int xh = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i + 1);
+    const int yl = (j == 0) ? 1 : (j == ny - 1 ? ny - 2 : j - 1);
+    const int yh = (j == 0) ? 1 : (j == ny - 1 ? ny - 2 : j + 1);
+    double un = 0.0;
+    un = un + u[xl + nx * j] * g.w[0] + u[xh + nx * j] * g.w[0];
+    un = un + u[i + nx * yl] * g.w[1] + u[i + nx * yh] * g.w[1];
+    u[i + nx * j] = (un - r) * g.w1;
+  };
+  auto point_of = [&](int p, int par, int &i, int &j) {
+    const int t = p % half;
+    j = g.lb[1] + p / half;
+    i = g.lb[0] + ((((g.lb[0] + j) & 1) != par) ? 1 : 0) + 2 * t;
+    return p < total && i <= g.ub[0];
+  };
+  // A thread's first KQ points of either colour are fixed for the whole call: their coordinates (-1: none) and
+  // right-hand side sit in registers - one integer division per point HERE instead of one per point and colour
+  // pass, and no global load inside the sweeps (each was a dependent ~1 us L2 round trip in front of a pass that
+  // has ~0.5 us of work).  Same expression per point: same bits.
+  int pij[2][KQ];
+  double rr[2][KQ];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      int i, j;
+      const bool have = point_of((int)threadIdx.x + 1024 * q, (g.first_par + pass) & 1, i, j);
+      pij[pass][q] = have ? (i | (j << 16)) : -1;
+      rr[pass][q] = (have && rhs_g) ? rhs_g[i + nx * j] : 0.0;
+    }
+  }
+  __syncthreads();
   for (int sw = 0; sw < nsweeps; ++sw) {
+#pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      const int par = (g.first_par + pass) & 1;
-      for (int p = threadIdx.x; p < total; p += blockDim.x) {
-        const int t = p % half, j = g.lb[1] + p / half;
-        const int i0 = g.lb[0] + ((((g.lb[0] + j) & 1) != par) ? 1 : 0);
-        const int i = i0 + 2 * t;
-        if (i > g.ub[0]) continue;
-        const int xl = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i - 1);
-        const int xh = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i + 1);
-        const int yl = (j == 0) ? 1 : (j == ny - 1 ? ny - 2 : j - 1);
-        const int yh = (j == 0) ? 1 : (j == ny - 1 ? ny - 2 : j + 1);
-        const double r = rhs_g ? rhs_g[i + nx * j] : 0.0;
-        double un = 0.0;  // ndsm_poisson.f90:603-617
-        un = un + u[xl + nx * j] * g.w[0] + u[xh + nx * j] * g.w[0];
-        un = un + u[i + nx * yl] * g.w[1] + u[i + nx * yh] * g.w[1];
-        u[i + nx * j] = (un - r) * g.w1;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const int c = pij[pass][q];
+        if (c >= 0) update(c & 0xffff, c >> 16, rr[pass][q]);
+        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four points' neighbour reads in flight at a time: registers)
+      }
+      for (int p = (int)threadIdx.x + 1024 * KQ; p < total; p += 1024) {   // (levels of more than 16384 points)
+        int i, j;
+        if (point_of(p, (g.first_par + pass) & 1, i, j)) update(i, j, rhs_g ? rhs_g[i + nx * j] : 0.0);
       }
       __syncthreads();
     }
     if (g.all_neumann) {
       double sm = 0.0;
-      for (int p = threadIdx.x; p < n; p += blockDim.x) sm = sm + u[p];
+#pragma unroll 8
+      for (int p = threadIdx.x; p < n; p += 1024) sm = sm + u[p];   // (unrolled: the reads overlap, the additions keep their order)
       for (int o = 32; o > 0; o >>= 1) sm = sm + __shfl_down(sm, o, 64);
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sm;
       __syncthreads();
       double tot = 0.0;
       for (int q = 0; q < 16; ++q) tot = tot + red[q];
       const double mean = tot / (double)n;
-      for (int p = threadIdx.x; p < n; p += blockDim.x) u[p] = u[p] - mean;
+#pragma unroll 8
+      for (int p = threadIdx.x; p < n; p += 1024) u[p] = u[p] - mean;
       __syncthreads();
     }
   }
