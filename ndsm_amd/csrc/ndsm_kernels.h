@@ -87,6 +87,11 @@ int ndsmk_free(void *p);
 int ndsmk_h2d(void *dst, const void *h_src, size_t bytes);   /* blocking */
 int ndsmk_d2h(void *h_dst, const void *src, size_t bytes);   /* blocking */
 int ndsmk_d2d(void *dst, const void *src, size_t bytes);
+// ghost planes of a smoothing pass: black points + perimeter only (halo.hip)
+long long ndsmk_halo_packed_plane(int nx, int ny);
+int ndsmk_halo_pack(const double *src, double *buf, int nx, int ny, int depth, int kg0, int first_par);
+int ndsmk_halo_unpack(double *dst, const double *buf, int nx, int ny, int depth, int kg0, int first_par);
+int ndsmk_halo_copy(double *dst, const double *src, int nx, int ny, int depth, int kg0, int first_par);
 int ndsmk_fill0(void *p, size_t bytes);
 int ndsmk_sync(void);                                        /* blocking */
 int ndsmk_timer_start(void);                /* hipEventRecord on the library stream */

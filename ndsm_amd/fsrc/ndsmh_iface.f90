@@ -86,6 +86,29 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_halo_packed_plane(nx, ny) bind(c, name="ndsmk_halo_packed_plane") result(n)
+      import :: c_int, c_long_long
+      integer(c_int), value :: nx, ny
+      integer(c_long_long) :: n
+    end function
+    function ndsmk_halo_pack(src, buf, nx, ny, depth, kg0, first_par) bind(c, name="ndsmk_halo_pack") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: src, buf
+      integer(c_int), value :: nx, ny, depth, kg0, first_par
+      integer(c_int) :: rc
+    end function
+    function ndsmk_halo_unpack(dst, buf, nx, ny, depth, kg0, first_par) bind(c, name="ndsmk_halo_unpack") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: dst, buf
+      integer(c_int), value :: nx, ny, depth, kg0, first_par
+      integer(c_int) :: rc
+    end function
+    function ndsmk_halo_copy(dst, src, nx, ny, depth, kg0, first_par) bind(c, name="ndsmk_halo_copy") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: dst, src
+      integer(c_int), value :: nx, ny, depth, kg0, first_par
+      integer(c_int) :: rc
+    end function
     function ndsmk_d2d(dst, src, bytes) bind(c, name="ndsmk_d2d") result(rc)
       import :: c_ptr, c_size_t, c_int
       type(c_ptr), value :: dst, src

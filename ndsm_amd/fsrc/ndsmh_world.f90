@@ -108,6 +108,11 @@ module ndsmh_world
     type(mg_solver), allocatable :: loc(:)
     type(slab_t), allocatable :: plan(:)     ! (0:nranks-1), identical on every rank
     integer :: ghost_depth = 0       ! this many ghost planes of u(1) per side match the neighbours' owned planes
+    ! ... and this many match them in what a SMOOTHING pass reads of a ghost plane - its black points and its
+    ! perimeter (exchange_sweep, halo.hip); >= ghost_depth
+    integer :: ghost_sweep = 0
+    type(c_ptr) :: hbuf(4) = c_null_ptr      ! packed planes: send up / receive from above / send down / receive from below
+    integer(ik) :: hbuf_planes = 0           ! capacity of each, in packed planes
     integer(ik) :: nzg = 0
     ! The coarse problem.  Null: levels >= 2 live on rank 0 (restricted planes are gathered there,
     ! corrections scattered back).  Associated: level 2 is distributed as well - a world of its
@@ -253,7 +258,7 @@ contains
       end if
       if (rc /= 0) return
     end do
-    w%ghost_depth = 0
+    w%ghost_depth = 0; w%ghost_sweep = 0
     if (dist) then
       allocate (w%child)
       rc = world_create(w%child, n2, lev(2)%ax(1)%q, lev(2)%ax(2)%q, lev(2)%ax(3)%q, bcs, ng - 1, nranks, rank, &
@@ -307,6 +312,11 @@ contains
       deallocate (w%loc)
     end if
     if (allocated(w%plan)) deallocate (w%plan)
+    do i = 1, 4
+      if (c_associated(w%hbuf(i))) rcf = ndsmk_free(w%hbuf(i))
+      w%hbuf(i) = c_null_ptr
+    end do
+    w%hbuf_planes = 0
     w%nlocal = 0
   end subroutine
 
@@ -335,7 +345,9 @@ contains
                      dptr_offset(host, int(a - gz0, c_size_t) * int(s%plane1, c_size_t) * R8), &
                      int(b - a, c_size_t) * int(s%plane1, c_size_t) * R8)
     end associate
-    if (which == MG_BUF_U) w%ghost_depth = 0
+    if (which == MG_BUF_U) then
+      w%ghost_depth = 0; w%ghost_sweep = 0
+    end if
     if (which == MG_BUF_RHS) call mg_mark_rhs_set(w%loc(ilocal))
   end function
 
@@ -513,15 +525,127 @@ contains
     end if
   end function
 
-  ! make at least `depth` ghost planes of u(1) per side current
-  function need_ghosts(w, depth) result(rc)
+  ! make at least `depth` ghost planes of u(1) per side current - sweep: in what a smoothing pass reads of them
+  ! (half the bytes: exchange_sweep); otherwise whole planes
+  function need_ghosts(w, depth, sweep) result(rc)
     type(mg_world), intent(inout) :: w
     integer, intent(in) :: depth
+    logical, intent(in), optional :: sweep
     integer(c_int) :: rc
+    logical :: sw
     rc = 0
-    if (w%ghost_depth >= depth) return
-    rc = exchange(w, MG_BUF_U, depth); if (rc /= 0) return
-    w%ghost_depth = depth
+    sw = .false.
+    if (present(sweep)) sw = sweep
+    if (sw) then
+      if (w%ghost_sweep >= depth) return
+      rc = exchange_sweep(w, depth); if (rc /= 0) return
+      w%ghost_sweep = max(w%ghost_sweep, depth)
+    else
+      if (w%ghost_depth >= depth) return
+      rc = exchange(w, MG_BUF_U, depth); if (rc /= 0) return
+      w%ghost_depth = depth
+      w%ghost_sweep = max(w%ghost_sweep, depth)
+    end if
+  end function
+
+  ! What a red-black sweep reads of a ghost plane is its black points as the neighbour last left them and the
+  ! points no sweep updates (Dirichlet data on the x / y faces): the red points are recomputed by the pass before
+  ! anything reads them.  So the halo of a smoothing pass travels as black points + perimeter - (nx ny) / 2 +
+  ! 2 (nx + ny) doubles per plane - packed by halo.hip (RCCL: pack, one grouped send / receive per neighbour,
+  ! unpack; loop-back worlds: the same points straight across).  NDSM_HIP_HALO_FULL=1: whole planes (A/B testing).
+  function exchange_sweep(w, depth) result(rc)
+    type(mg_world), intent(inout) :: w
+    integer, intent(in) :: depth
+    integer(c_int) :: rc, rc2
+    integer :: i, r, g, nown, st, q
+    integer(c_int) :: nx, ny, fp, d
+    integer(ik) :: cnt
+    integer(c_size_t) :: pl, pk
+    type(c_ptr) :: me, nbr
+    logical, save :: first = .true., full = .false.
+    rc = 0
+    if (w%nranks == 1) return
+    if (first) then
+      call get_environment_variable("NDSM_HIP_HALO_FULL", status=st)
+      full = (st == 0)
+      first = .false.
+    end if
+    if (full) then
+      rc = exchange(w, MG_BUF_U, depth)
+      return
+    end if
+    d = int(depth, c_int)
+    if (w%rccl) then
+      associate (s => w%loc(1))
+        nx = s%lev(1)%g%n(1); ny = s%lev(1)%g%n(2)
+        pk = int(ndsmk_halo_packed_plane(nx, ny), c_size_t)
+        if (w%hbuf_planes < depth) then
+          do q = 1, 4
+            if (c_associated(w%hbuf(q))) rc2 = ndsmk_free(w%hbuf(q))
+            w%hbuf(q) = c_null_ptr
+          end do
+          w%hbuf_planes = max(int(depth, ik), int(w%plan(0)%g, ik))
+          do q = 1, 4
+            rc = ndsmk_alloc(w%hbuf(q), int(w%hbuf_planes, c_size_t) * pk * R8); if (rc /= 0) return
+          end do
+        end if
+      end associate
+    end if
+    ! (1) RCCL: pack what goes up / down
+    if (w%rccl) then
+      associate (s => w%loc(1))
+        r = s%sl%rank; g = s%sl%g; nown = s%sl%z1 - s%sl%z0
+        pl = int(s%plane1, c_size_t); fp = s%lev(1)%g%first_par
+        me = mg_level_ptr(s, 1, MG_BUF_U, cnt)
+        if (r < w%nranks - 1) then
+          rc = ndsmk_halo_pack(dptr_offset(me, int(g + nown - depth, c_size_t) * pl * R8), w%hbuf(1), nx, ny, d, &
+                               int(s%sl%k0 + g + nown - depth, c_int), fp); if (rc /= 0) return
+        end if
+        if (r > 0) then
+          rc = ndsmk_halo_pack(dptr_offset(me, int(g, c_size_t) * pl * R8), w%hbuf(3), nx, ny, d, &
+                               int(s%sl%k0 + g, c_int), fp); if (rc /= 0) return
+        end if
+        rc = ndsmk_dist_group_start(); if (rc /= 0) return
+        if (r < w%nranks - 1) then
+          rc = ndsmk_dist_send(w%hbuf(1), int(depth, c_size_t) * pk, int(r + 1, c_int))
+          if (rc == 0) rc = ndsmk_dist_recv(w%hbuf(2), int(depth, c_size_t) * pk, int(r + 1, c_int))
+        end if
+        if (rc == 0 .and. r > 0) then
+          rc = ndsmk_dist_send(w%hbuf(3), int(depth, c_size_t) * pk, int(r - 1, c_int))
+          if (rc == 0) rc = ndsmk_dist_recv(w%hbuf(4), int(depth, c_size_t) * pk, int(r - 1, c_int))
+        end if
+        rc2 = ndsmk_dist_group_end()       ! (an open group must be closed whatever happened inside)
+        if (rc == 0) rc = rc2
+        if (rc /= 0) return
+        if (r < w%nranks - 1) then
+          rc = ndsmk_halo_unpack(dptr_offset(me, int(g + nown, c_size_t) * pl * R8), w%hbuf(2), nx, ny, d, &
+                                 int(s%sl%k0 + g + nown, c_int), fp); if (rc /= 0) return
+        end if
+        if (r > 0) then
+          rc = ndsmk_halo_unpack(dptr_offset(me, int(g - depth, c_size_t) * pl * R8), w%hbuf(4), nx, ny, d, &
+                                 int(s%sl%k0 + g - depth, c_int), fp); if (rc /= 0) return
+        end if
+      end associate
+      return
+    end if
+    ! (2) loop-back: slab i and its upper neighbour i + 1 trade straight across
+    do i = 1, w%nlocal - 1
+      associate (s => w%loc(i), t => w%loc(i + 1))
+        g = s%sl%g; nown = s%sl%z1 - s%sl%z0
+        pl = int(s%plane1, c_size_t); fp = s%lev(1)%g%first_par
+        nx = s%lev(1)%g%n(1); ny = s%lev(1)%g%n(2)
+        me = mg_level_ptr(s, 1, MG_BUF_U, cnt)
+        nbr = mg_level_ptr(t, 1, MG_BUF_U, cnt)
+        ! my last owned planes -> its lower ghosts
+        rc = ndsmk_halo_copy(dptr_offset(nbr, int(t%sl%g - depth, c_size_t) * pl * R8), &
+                             dptr_offset(me, int(g + nown - depth, c_size_t) * pl * R8), nx, ny, d, &
+                             int(s%sl%k0 + g + nown - depth, c_int), fp); if (rc /= 0) return
+        ! its first owned planes -> my upper ghosts
+        rc = ndsmk_halo_copy(dptr_offset(me, int(g + nown, c_size_t) * pl * R8), &
+                             dptr_offset(nbr, int(t%sl%g, c_size_t) * pl * R8), nx, ny, d, &
+                             int(s%sl%k0 + g + nown, c_int), fp); if (rc /= 0) return
+      end associate
+    end do
   end function
 
   ! May a pass with exchange depth d run its interior while the halo travels?  More than one rank,
@@ -610,13 +734,13 @@ contains
       end if
       mt = 0
       if (domet) mt = 1
-      if (res .and. left == 1 .and. w%ghost_depth < 3 .and. overlap_ok(w, 3)) then
+      if (res .and. left == 1 .and. w%ghost_sweep < 3 .and. overlap_ok(w, 3)) then
         ! the sweep + residual pass in three pieces as well: its exchange (3 planes: one more for the
         ! residual's stencil) on the communication stream behind the planes that do not need it
         d = 3
         rc = ndsmk_stream_fence(0_c_int, 1_c_int); if (rc /= 0) return
         rc = ndsmk_select_stream(1_c_int); if (rc /= 0) return
-        rc = exchange(w, MG_BUF_U, d)
+        rc = exchange_sweep(w, d)
         i = ndsmk_select_stream(0_c_int)
         if (rc /= 0) return
         do i = 1, w%nlocal
@@ -633,18 +757,18 @@ contains
           end associate
         end do
       else if (res .and. left == 1) then
-        rc = need_ghosts(w, 3); if (rc /= 0) return
+        rc = need_ghosts(w, 3, sweep=.true.); if (rc /= 0) return
         do i = 1, w%nlocal
           rc = mg_op(w%loc(i), MG_OP_RELAX_RES_FUSED, 1, 1); if (rc /= 0) return
         end do
-      else if (w%ghost_depth < 2 * n .and. overlap_ok(w, 2 * n)) then
+      else if (w%ghost_sweep < 2 * n .and. overlap_ok(w, 2 * n)) then
         ! the halo exchange of this pass on the communication stream, the planes that do not need
         ! it meanwhile, the 2n planes next to each neighbour once it has arrived (out of place:
         ! all three launches read u and write disjoint planes of its partner)
         d = 2 * n
         rc = ndsmk_stream_fence(0_c_int, 1_c_int); if (rc /= 0) return
         rc = ndsmk_select_stream(1_c_int); if (rc /= 0) return
-        rc = exchange(w, MG_BUF_U, d)
+        rc = exchange_sweep(w, d)
         i = ndsmk_select_stream(0_c_int)
         if (rc /= 0) return
         do i = 1, w%nlocal
@@ -662,7 +786,7 @@ contains
           end associate
         end do
       else
-        rc = need_ghosts(w, 2 * n); if (rc /= 0) return
+        rc = need_ghosts(w, 2 * n, sweep=.true.); if (rc /= 0) return
         do i = 1, w%nlocal
           if (pro .or. domet) then
             rc = window_pass(w, i, n, int(w%loc(i)%lev(1)%g%zown0), int(w%loc(i)%lev(1)%g%zown1), pro, mt)
@@ -681,7 +805,7 @@ contains
         end do
         w%protect = .false.
       end if
-      w%ghost_depth = 0
+      w%ghost_depth = 0; w%ghost_sweep = 0
       left = left - n
     end do
   end function
@@ -708,7 +832,7 @@ contains
     do i = 1, w%nlocal
       rc = mg_slab_prolong(w%loc(i), w%psrc(i), w%psk0(i)); if (rc /= 0) return
     end do
-    w%ghost_depth = 0
+    w%ghost_depth = 0; w%ghost_sweep = 0
   end function
 
   recursive function world_vcycle(w) result(rc)
@@ -770,7 +894,7 @@ contains
           c%loc(i)%ms = w%loc(i)%ms
         end do
         rc = exchange(c, MG_BUF_RHS, c%plan(0)%g); if (rc /= 0) return   ! redundant ghost updates read rhs there
-        c%ghost_depth = c%plan(0)%g                                        ! u = 0 everywhere: ghosts are current
+        c%ghost_depth = c%plan(0)%g; c%ghost_sweep = c%plan(0)%g                                        ! u = 0 everywhere: ghosts are current
         rc = world_vcycle(c); if (rc /= 0) return
         rc = world_relax(c, c%loc(1)%ms); if (rc /= 0) return
         rc = need_ghosts(c, c%plan(0)%g); if (rc /= 0) return
@@ -812,7 +936,7 @@ contains
         w%psrc(i) = w%loc(i)%cbuf; w%psk0(i) = w%loc(i)%sl%cb0; w%psn(i) = w%loc(i)%sl%cb1 - w%loc(i)%sl%cb0
       end do
     end if
-    w%ghost_depth = 0
+    w%ghost_depth = 0; w%ghost_sweep = 0
     rc = world_relax(w, w%loc(1)%ms, prolong=.true., last=w%want_met)
   end function
 
@@ -1060,7 +1184,7 @@ contains
             c%loc(i)%ms = w%loc(i)%ms
           end do
           rc = exchange(c, MG_BUF_RHS, c%plan(0)%g); if (rc /= 0) return
-          c%ghost_depth = c%plan(0)%g
+          c%ghost_depth = c%plan(0)%g; c%ghost_sweep = c%plan(0)%g
           rc = world_vcycle(c); if (rc /= 0) return
           rc = world_relax(c, c%loc(1)%ms); if (rc /= 0) return
           rc = need_ghosts(c, c%plan(0)%g); if (rc /= 0) return
@@ -1109,7 +1233,7 @@ contains
           tot(1) = max(tot(1), met(1)); tot(2) = tot(2) + met(2)
         end associate
       end do
-      w%ghost_depth = 0                 ! u' was written on owned planes only
+      w%ghost_depth = 0; w%ghost_sweep = 0                 ! u' was written on owned planes only
       w%eghost = g                      ! e = 0 everywhere
       rc = exchange_f32(w, w%r32, g); if (rc /= 0) return
       if (w%rccl) then
