@@ -211,6 +211,7 @@ int ndsmk_fused_prolong_ok(const ndsmk_grid *g, const double *rhs, int nsweeps);
 #define NDSMK_LANES 6
 int ndsmk_select_lane(int lane);           /* -1: main stream */
 int ndsmk_lane_fence(int lane, int to_main);
+int ndsmk_lane_idle(int lane);   /* 1: the lane's stream has drained, 0: not yet (never blocks), < 0: error */
 int ndsmk_lane_sync(int lane);
 int ndsmk_capture_begin(void);             /* record what is enqueued on the selected lane ... */
 int ndsmk_capture_end(void **exec);        /* ... into an executable graph */

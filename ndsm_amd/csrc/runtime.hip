@@ -395,6 +395,17 @@ int ndsmk_lane_fence(int lane, int to_main) {
   }
   return 0;
 }
+// has everything enqueued on the lane's stream finished?  1 yes, 0 not yet (never blocks), < 0: error
+int ndsmk_lane_idle(int lane) {
+  if (!ndsm::ready() || lane < 0 || lane >= NDSMK_LANES || !g_rt.lane[lane]) return -1;
+  const hipError_t e = hipStreamQuery(g_rt.lane[lane]);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return -1;
+}
 // Graphs: a launch-bound sequence that repeats unchanged (one V-cycle + metric of a small 2-D solve: ~190
 // launches of a few microseconds) is recorded once from the selected lane's stream and replayed as ONE graph launch.
 // ndsmk_capture_begin(): everything enqueued on the selected lane from now on is recorded, not executed;

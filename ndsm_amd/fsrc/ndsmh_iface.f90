@@ -219,6 +219,11 @@ module ndsmh_iface
       integer(c_int) :: rc
     end function
 
+    function ndsmk_lane_idle(lane) bind(c, name="ndsmk_lane_idle") result(rc)
+      import :: c_int
+      integer(c_int), value :: lane
+      integer(c_int) :: rc
+    end function
     function ndsmk_lane_fence(lane, to_main) bind(c, name="ndsmk_lane_fence") result(rc)
       import :: c_int
       integer(c_int), value :: lane, to_main

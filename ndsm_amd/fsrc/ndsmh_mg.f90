@@ -990,6 +990,15 @@ contains
     do while (any(active(1:nl)))
       do l = 1, nl
         if (.not. active(l)) cycle
+        ! (the host serves whichever lane has finished, not the lanes in turn: a lane that is still busy is passed
+        ! over - unless it is the only one left, then the host may as well sleep in the wait)
+        if (count(active(1:nl)) > 1) then
+          rc = ndsmk_lane_idle(int(l - 1, c_int))
+          if (rc < 0) then
+            rc = NDSMK_EARG; goto 800
+          end if
+          if (rc == 0) cycle
+        end if
         rc = ndsmk_select_lane(int(l - 1, c_int)); if (rc /= 0) goto 800
         rc = ndsmk_diff_metrics_end(met); if (rc /= 0) goto 800
         if (ss(l)%use_max) then
