@@ -238,6 +238,7 @@ def test_bench_lone_process_starts_its_own_ranks(hip):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4 and out["slab_mode"] is True and out["rccl_ranks"] == 4
     assert "MISMATCH" not in out["slab_check"], out["slab_check"]
+    assert "chosen by a 3-cycle trial" in out["slab_check"], out["slab_check"]     # both schedules passed: the faster one is timed
     assert "REHEARSAL SHAPE" in out["config"]["workload"]
     assert out["roofline"]["frac"] is None and out["roofline"]["frac_algorithmic"] > 0     # no counter figure in slab mode
 
