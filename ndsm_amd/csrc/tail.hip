@@ -213,6 +213,13 @@ __device__ __forceinline__ void residual(const double *u, const double *rhs, dou
   __syncthreads();
 }
 
+// the largest value of v over the lanes of the wave, as a wave-uniform number (lanes without a point pass 0)
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
 // rhs_c = R r_f, u_c = 0 (restrict_k<3>: weight chain ((((c2x w2x) c2y) w2y) c2z) w2z, taps summed x fastest)
 #define TAB(T, off) reinterpret_cast<const T *>(ldsb + (off))
 __device__ __forceinline__ void restrict_to(const double *f, double *rhs_c, double *u_c, const ndsmk_grid &gf,
@@ -221,12 +228,17 @@ __device__ __forceinline__ void restrict_to(const double *f, double *rhs_c, doub
   const int nc = ncx * ncy * ncz;
   const int sy = gf.n[0], sz = gf.n[0] * gf.n[1];
   if (gf.ndim == 2) {  // restrict_k<2>
-    for (int c = (int)threadIdx.x; c < nc; c += kT) {
-      const int I = c % ncx, J = c / ncx;
-      const int i0 = TAB(int32_t, x.o_rlo[0])[I], ni = TAB(int32_t, x.o_rcnt[0])[I];
-      const int j0 = TAB(int32_t, x.o_rlo[1])[J], nj = TAB(int32_t, x.o_rcnt[1])[J];
+    // (every wave runs the same number of rounds so that wave_max sees whole waves; the tap loops stop at the
+    // wave's largest tap counts - typically 4 or 5 of the kRT = 6 slots per dimension - and stay predicated per lane)
+    for (int c0 = 0; c0 < nc; c0 += kT) {
+      const int c = c0 + (int)threadIdx.x;
+      const bool have = c < nc;
+      const int I = have ? c % ncx : 0, J = have ? c / ncx : 0;
+      const int i0 = TAB(int32_t, x.o_rlo[0])[I], ni = have ? TAB(int32_t, x.o_rcnt[0])[I] : 0;
+      const int j0 = TAB(int32_t, x.o_rlo[1])[J], nj = have ? TAB(int32_t, x.o_rcnt[1])[J] : 0;
       const double *cx = TAB(double, x.o_rw[0]) + I * x.maxt[0];
       const double *cy = TAB(double, x.o_rw[1]) + J * x.maxt[1];
+      const int nim = wave_max(ni), njm = wave_max(nj);
       double wx[kRT], wy[kRT];
 #pragma unroll
       for (int q = 0; q < kRT; ++q) {
@@ -236,35 +248,43 @@ __device__ __forceinline__ void restrict_to(const double *f, double *rhs_c, doub
       double fc = 0.0;
 #pragma unroll
       for (int jj = 0; jj < kRT; ++jj) {
-        if (jj < nj) {
+        if (jj < njm) {
           const double *row = f + i0 + sy * (j0 + jj);
 #pragma unroll
           for (int ii = 0; ii < kRT; ++ii) {
-            if (ii < ni) {
-              double w = wx[ii] * x.w2[0];
-              w = w * wy[jj] * x.w2[1];
-              fc = fc + w * row[ii];
+            if (ii < nim) {
+              if (jj < nj && ii < ni) {
+                double w = wx[ii] * x.w2[0];
+                w = w * wy[jj] * x.w2[1];
+                fc = fc + w * row[ii];
+              }
             }
           }
         }
       }
-      rhs_c[c] = fc;
-      u_c[c] = 0.0;
+      if (have) {
+        rhs_c[c] = fc;
+        u_c[c] = 0.0;
+      }
     }
     __syncthreads();
     return;
   }
-  for (int c = (int)threadIdx.x; c < nc; c += kT) {
-    const int I = c % ncx, J = (c / ncx) % ncy, K = c / (ncx * ncy);
-    const int i0 = TAB(int32_t, x.o_rlo[0])[I], ni = TAB(int32_t, x.o_rcnt[0])[I];
-    const int j0 = TAB(int32_t, x.o_rlo[1])[J], nj = TAB(int32_t, x.o_rcnt[1])[J];
-    const int k0 = TAB(int32_t, x.o_rlo[2])[K], nk = TAB(int32_t, x.o_rcnt[2])[K];
+  for (int c0 = 0; c0 < nc; c0 += kT) {
+    const int c = c0 + (int)threadIdx.x;
+    const bool have = c < nc;
+    const int I = have ? c % ncx : 0, J = have ? (c / ncx) % ncy : 0, K = have ? c / (ncx * ncy) : 0;
+    const int i0 = TAB(int32_t, x.o_rlo[0])[I], ni = have ? TAB(int32_t, x.o_rcnt[0])[I] : 0;
+    const int j0 = TAB(int32_t, x.o_rlo[1])[J], nj = have ? TAB(int32_t, x.o_rcnt[1])[J] : 0;
+    const int k0 = TAB(int32_t, x.o_rlo[2])[K], nk = have ? TAB(int32_t, x.o_rcnt[2])[K] : 0;
     const double *cx = TAB(double, x.o_rw[0]) + I * x.maxt[0];
     const double *cy = TAB(double, x.o_rw[1]) + J * x.maxt[1];
     const double *cz = TAB(double, x.o_rw[2]) + K * x.maxt[2];
-    // fixed-bound loops with the taps predicated and the weights fetched up front (as restrict_k): measured
-    // faster than per-lane trip counts (8.4 against 9.9 us for 16^3 -> 8^3) - the few waves at work here wait
-    // for the length of their own instruction stream either way
+    // Tap loops with the taps predicated per lane and the weights fetched up front (as restrict_k) - measured faster
+    // than per-lane trip counts (8.4 against 9.9 us for 16^3 -> 8^3) - but (round 3) stopped at the WAVE's largest
+    // tap counts, wave-uniform numbers: 4 or 5 of the kRT = 6 slots per dimension instead of all 216 predicated
+    // rounds (the few waves at work here wait for the length of their own instruction stream)
+    const int nim = wave_max(ni), njm = wave_max(nj), nkm = wave_max(nk);
     double wx[kRT], wy[kRT], wz[kRT];
 #pragma unroll
     for (int q = 0; q < kRT; ++q) {
@@ -275,27 +295,31 @@ __device__ __forceinline__ void restrict_to(const double *f, double *rhs_c, doub
     double fc = 0.0;
 #pragma unroll
     for (int kk = 0; kk < kRT; ++kk) {
-      if (kk < nk) {
+      if (kk < nkm) {
         const double c2z = wz[kk];
 #pragma unroll
         for (int jj = 0; jj < kRT; ++jj) {
-          if (jj < nj) {
+          if (jj < njm) {
             const double *row = f + i0 + sy * (j0 + jj) + sz * (k0 + kk);
 #pragma unroll
             for (int ii = 0; ii < kRT; ++ii) {
-              if (ii < ni) {
-                double w = wx[ii] * x.w2[0];  // 1 * c2 * w2 (ndsm_interp.f90:277-282)
-                w = w * wy[jj] * x.w2[1];
-                w = w * c2z * x.w2[2];
-                fc = fc + w * row[ii];
+              if (ii < nim) {
+                if (kk < nk && jj < nj && ii < ni) {
+                  double w = wx[ii] * x.w2[0];  // 1 * c2 * w2 (ndsm_interp.f90:277-282)
+                  w = w * wy[jj] * x.w2[1];
+                  w = w * c2z * x.w2[2];
+                  fc = fc + w * row[ii];
+                }
               }
             }
           }
         }
       }
     }
-    rhs_c[c] = fc;
-    u_c[c] = 0.0;  // ndsm_multigrid_core.f90:557-558
+    if (have) {
+      rhs_c[c] = fc;
+      u_c[c] = 0.0;  // ndsm_multigrid_core.f90:557-558
+    }
   }
   __syncthreads();
 }
