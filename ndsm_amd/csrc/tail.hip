@@ -101,6 +101,9 @@ __device__ __forceinline__ void make_set(const ndsmk_grid &g, int par, int u_off
 }
 
 // one colour pass (ndsm_optimized.f90:123-129; the expression of rbgs3_small / rbgs3_color)
+// WAVE: the level lives in ONE wave (exact's single-wave form): the LDS operations of a wave execute in program
+// order, so what a lane wrote is there for the lane that reads it next - no workgroup barrier
+template <bool WAVE = false>
 __device__ __forceinline__ void colour_pass(char *ldsb, const ndsmk_grid &g, const PtSet &s) {
 #define LD(off) (*reinterpret_cast<const double *>(ldsb + (off)))
 #pragma unroll
@@ -112,11 +115,15 @@ __device__ __forceinline__ void colour_pass(char *ldsb, const ndsmk_grid &g, con
     }
   }
 #undef LD
-  __syncthreads();
+  if (WAVE)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  else
+    __syncthreads();
 }
 
 // 2-D (ndsm_poisson.f90:603-617; the expression of rbgs2_small / rbgs2_color - the point sets are the 3-D ones
 // with one plane: stencil_stride's collapsed boundary neighbours are the mirrored ones)
+template <bool WAVE = false>
 __device__ __forceinline__ void colour_pass2(char *ldsb, const ndsmk_grid &g, const PtSet &s) {
 #define LD(off) (*reinterpret_cast<const double *>(ldsb + (off)))
 #pragma unroll
@@ -129,7 +136,10 @@ __device__ __forceinline__ void colour_pass2(char *ldsb, const ndsmk_grid &g, co
     }
   }
 #undef LD
-  __syncthreads();
+  if (WAVE)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  else
+    __syncthreads();
 }
 
 // u -= mean(u) after a sweep of an all-Neumann problem (ndsm_poisson.f90:534-547), summed as rbgs2_small /
@@ -153,6 +163,39 @@ __device__ __forceinline__ void relax(double *lds, int u_off, int rhs_off, const
   make_set(g, g.first_par & 1, u_off, lds + rhs_off, a);
   make_set(g, (g.first_par + 1) & 1, u_off, lds + rhs_off, b);
   char *const ldsb = reinterpret_cast<char *>(lds);
+  if (g.n[0] * g.n[1] * g.n[2] <= 64) {
+    // a level of at most 64 points (8 x 8, 4 x 4 (x 4)) lives in ONE wave: the same sweeps and - for the mean of an
+    // all-Neumann 2-D level - the same sum in the same order (mean_shift's partials of waves 1..15 are exact zeros
+    // and are added as such), without the two to four workgroup barriers per sweep
+    const int n = g.n[0] * g.n[1] * g.n[2];
+    if (threadIdx.x < 64) {
+      double *u = lds + u_off;
+      const bool mine = (int)threadIdx.x < n;
+      for (int sw = 0; sw < nsweeps; ++sw) {
+        if (g.ndim == 3) {
+          colour_pass<true>(ldsb, g, a);
+          colour_pass<true>(ldsb, g, b);
+        } else {
+          colour_pass2<true>(ldsb, g, a);
+          colour_pass2<true>(ldsb, g, b);
+          if (g.all_neumann) {
+            double sm = mine ? 0.0 + u[threadIdx.x] : 0.0;
+            for (int o = 32; o > 0; o >>= 1) sm = sm + __shfl_down(sm, o, 64);
+            sm = __shfl(sm, 0, 64);
+            double tot = 0.0;
+            tot = tot + sm;
+#pragma unroll
+            for (int q = 1; q < kT / 64; ++q) tot = tot + 0.0;
+            const double mean = tot / (double)n;
+            if (mine) u[threadIdx.x] = u[threadIdx.x] - mean;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          }
+        }
+      }
+    }
+    __syncthreads();
+    return;
+  }
   if (g.ndim == 3) {
     for (int sw = 0; sw < nsweeps; ++sw) {
       colour_pass(ldsb, g, a);
@@ -399,6 +442,63 @@ __device__ __forceinline__ int exact(double *lds, int u_off, int rhs_off, double
   double du = 1.79769313486231570815e308;
   int sweeps = 0;
   *conv = 0;
+  if (n <= 64) {
+    // The coarsest grid of NDSM's hierarchies - 4 x 4 (x 4) points - fits ONE wave: the same sweeps, the same sums in
+    // the same order (solve_exact_k's partials of waves 1..3 are exact zeros here and are added as such), but no
+    // workgroup barrier inside the loop - five (three in 3-D) barriers of ~0.45 us per sweep were the whole cost
+    // of it: 2.3 -> 0.3 us per sweep (a 128^2 face cycle spends 17 sweeps here).  The other 15 waves wait at the end.
+    if (threadIdx.x < 64) {
+      double *uw = lds + u_off;
+      const bool mine = (int)threadIdx.x < n;
+      for (int it = 0; it < nmax; ++it) {
+        if (du <= ex_tol) {
+          *conv = 1;
+          break;
+        }
+        if (g.ndim == 3) {
+          colour_pass<true>(ldsb, g, a);
+          colour_pass<true>(ldsb, g, b);
+        } else {
+          colour_pass2<true>(ldsb, g, a);
+          colour_pass2<true>(ldsb, g, b);
+        }
+        if (g.all_neumann) {
+          double sm1 = mine ? 0.0 + uw[threadIdx.x] : 0.0;
+          for (int o = 32; o > 0; o >>= 1) sm1 = sm1 + __shfl_down(sm1, o, 64);
+          sm1 = __shfl(sm1, 0, 64);
+          const double mean = (((sm1 + 0.0) + 0.0) + 0.0) / (double)n;
+          if (mine) uw[threadIdx.x] = uw[threadIdx.x] - mean;
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        double mx = 0.0, sm = 0.0;
+        if (mine) {
+          const double d = fabs(sav[threadIdx.x] - uw[threadIdx.x]);
+          mx = fmax(mx, d);
+          sm = sm + d;
+          sav[threadIdx.x] = uw[threadIdx.x];
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+          mx = fmax(mx, __shfl_down(mx, o, 64));
+          sm = sm + __shfl_down(sm, o, 64);
+        }
+        mx = __shfl(mx, 0, 64);
+        sm = __shfl(sm, 0, 64);
+        mx = fmax(fmax(mx, 0.0), fmax(0.0, 0.0));
+        sm = ((sm + 0.0) + 0.0) + 0.0;
+        du = use_max ? mx : sm / (double)n;
+        ++sweeps;
+      }
+      if (threadIdx.x == 0) {
+        red[8] = (double)sweeps;
+        red[9] = (double)*conv;
+      }
+    }
+    __syncthreads();
+    sweeps = (int)red[8];
+    *conv = (int)red[9];
+    __syncthreads();   // (red is written again by the sweeps that follow)
+    return sweeps;
+  }
   for (int it = 0; it < nmax; ++it) {
     if (du <= ex_tol) {  // uniform: every thread holds the same du
       *conv = 1;
